@@ -1,0 +1,143 @@
+/* wf_dwfst.h -- C ABI of libwfdwfst.so: the MI355X (gfx950) DWFST loss / Viterbi hot path.
+ *
+ * This is the drop-in boundary for the k2 calls made by the reference
+ * (ZhaoZeyu1995/Waterfall, paths below are relative to that repository):
+ *
+ *   waterfall/graph.py:61-66     k2.intersect_dense(graph, dense, output_beam)
+ *                                + lattice.get_tot_scores(log_semiring=True, use_double_scores)
+ *                                + the autograd backward of both        -> wf_fb_logsum()
+ *   waterfall/models.py:256-261  k2.DenseFsaVec(log_probs, supervision_segments)
+ *                                -> no copy is made: (log_probs pointer, strides, seg[B,3]) is the
+ *                                   dense FSA vector; wf_fb_logsum()/wf_viterbi() take it directly
+ *   utils/lattice_analysis.py:129,149,155  get_tot_scores(True, False) (tropical)  -> wf_tot_scores()
+ *   utils/lattice_analysis.py:79,133,158   k2.shortest_path / one_best_decoding    -> wf_viterbi()
+ *   waterfall/models.py:263-270  linear_fsa -> remove_epsilon_and_add_self_loops -> arc_sort ->
+ *                                compose(topo, ., treat_epsilons_specially=False)  -> wf_compose_linear()
+ *   waterfall/manual_ctc/ctc.py:94-105  ctc_loss(log_probs, input_lengths, trans, trans_lengths,
+ *                                transform): converted to a graph on the host (Python, manual_ctc.py)
+ *                                and run through wf_fb_logsum()
+ *
+ * The reference reaches k2 through pybind; it has no FFI of its own.  The reference-side binding a
+ * maintainer would add is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures (hipStream_t is passed as
+ *     void*; NULL = the default stream).
+ *   - every function returns 0 on success or a negative WF_E* code; wf_last_error() returns a
+ *     thread-local message.  No C++ exception crosses this boundary.
+ *   - the library never allocates or frees device memory and keeps no pointer after returning:
+ *     the caller allocates outputs and the workspace (size from wf_fb_workspace_bytes()).
+ *   - device work is stream-ordered and asynchronous; no host synchronisation inside.
+ *   - an utterance whose graph has no path of its length is NOT an error: tot = -inf, grad = 0.
+ *
+ * Graph layout (host side, k2's Fsa layout): arcs int32[A][4] = {src, dst, label, score_bits}
+ * with state ids local to their FSA, arcs of one FSA contiguous; start state 0; the last state
+ * of every FSA is the super-final state, entered only by label -1 arcs; labels >= 0 index the
+ * last dimension of log_probs.
+ */
+#ifndef WF_DWFST_H_
+#define WF_DWFST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WF_OK 0
+#define WF_EINVAL (-1)    /* bad argument / malformed graph          */
+#define WF_ENOSPC (-2)    /* caller buffer / workspace too small     */
+#define WF_ERANGE (-3)    /* label >= V, state out of range, ...     */
+#define WF_EHIP (-4)      /* a HIP runtime call failed               */
+#define WF_EUNSUPPORTED (-5)
+
+/* flags for wf_fb_logsum / wf_tot_scores / wf_viterbi */
+#define WF_DOUBLE_ACC 1u  /* accumulate alpha/beta in fp64 (k2 use_double_scores=True)            */
+#define WF_TROPICAL 2u    /* wf_tot_scores only: max instead of log-sum-exp                       */
+#define WF_KEEP_AB 4u     /* wf_fb_logsum with grad == NULL: still run both sweeps and leave alpha/
+                             beta in the workspace so that wf_fb_backward() can follow later       */
+
+typedef struct {
+    int32_t num_fsas;                 /* G                                                     */
+    const int32_t* arcs;              /* host, [num_arcs][4]                                   */
+    const int32_t* fsa_arc_offsets;   /* host, [G+1]                                           */
+    const int32_t* fsa_num_states;    /* host, [G]                                             */
+} wf_graph_host;
+
+int wf_version(void);
+const char* wf_last_error(void);
+
+/* ---- graph preparation (host only, no GPU needed) ------------------------------------------
+ * Builds the position-independent "prepared graph": per FSA the incoming-arc CSR (forward sweep),
+ * outgoing-arc CSR (backward sweep), label-sorted arc lists (posterior reduction), final arcs and
+ * the compact label table.  The caller copies the blob to the device once per graph and passes
+ * both copies to the compute calls (the host copy is read for launch planning only).
+ * Replaces what k2 does inside Fsa construction / arc_sort (datapipe.py:180, models.py:267).   */
+int wf_graph_prepare_bytes(const wf_graph_host* g, size_t* bytes);
+int wf_graph_prepare(const wf_graph_host* g, void* blob_host, size_t bytes);
+
+/* ---- numerator graph compiler (host) --------------------------------------------------------
+ * compose(topo, linear transcript with epsilon self-loops), models.py:263-270.
+ * topo: one FSA (arcs + aux = output phone label, 0 = epsilon, -1 on final arcs).
+ * Two-call protocol: with out_arcs == NULL only the sizes are written.                          */
+int wf_compose_linear(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs,
+                      int32_t topo_num_states, const int32_t* phones, int32_t num_phones,
+                      int32_t* out_arcs, int32_t* out_aux, int32_t* out_num_arcs,
+                      int32_t* out_num_states, int32_t arc_capacity);
+
+/* ---- workspace ------------------------------------------------------------------------------
+ * utt2fsa: host [B] FSA index used by utterance i, or NULL for the identity (B == G); a single
+ * shared denominator topology (rnnp.py:91-92) is utt2fsa = {0,0,...}.
+ * seg: host int32 [B][3] = {sequence index b, start frame, num frames} (models.py:256-258).     */
+int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
+                          int32_t B, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes);
+
+/* ---- log-semiring forward-backward: total scores and gradient (graph.py:61-66 + autograd) ---
+ * log_probs: device fp32, element (b,t,v) at b*strideB + t*strideT + v.
+ * output_beam: <= 0 or +inf disables pruning (exact sum over all lattice arcs); otherwise arcs
+ *   whose best path is more than output_beam below the best path are dropped.
+ * grad_scale: DEVICE fp32 [B] or NULL(=1): grad[b,t,v] = grad_scale[i] * sum of arc posteriors,
+ *   i.e. -1 for d(-tot)/d log_probs, -1/(B*target_len) for reduction 'mean' (graph.py:74-76).
+ * tot: device fp32 [B].  grad: device fp32, same strides as log_probs, every element of the
+ *   B x Tmax x V box named by seg rows is overwritten (zeros outside the segments' frames);
+ *   NULL = forward only (e.g. a denominator under torch.no_grad(), conformer.py:413).
+ * Tmax: number of frames per sequence in the grad tensor.                                        */
+int wf_fb_logsum(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                 const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
+                 int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,
+                 uint32_t flags, const float* grad_scale, float* tot, float* grad,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- deferred gradient: the autograd backward of graph.py:61-66 --------------------------------
+ * Must follow a wf_fb_logsum(..., flags | WF_KEEP_AB, grad = NULL, same graph / seg / workspace) on
+ * the same stream: reads alpha/beta/tot left there and writes grad rows scaled by grad_scale (the
+ * upstream d loss / d tot_b, a DEVICE array, so no host synchronisation is needed).               */
+int wf_fb_backward(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                   const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
+                   int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, uint32_t flags,
+                   const float* grad_scale, const float* tot, float* grad,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- total scores only, log or tropical (lattice_analysis.py:128-129) ------------------------
+ * tot: device fp32 [B] (or fp64 [B] when WF_DOUBLE_ACC is set).                                 */
+int wf_tot_scores(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                  const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
+                  const int32_t* seg, int32_t B, uint32_t flags, void* tot,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- tropical best path (k2.shortest_path / one_best_decoding) -------------------------------
+ * best_score device fp32 [B]; best_arcs device int32 [B][Tmax+1]: arc indices into the FsaVec's
+ * arc array (T_b emitting arcs then the final arc; -1 padded; all -1 when infeasible).
+ * Ties are broken by the lowest arc index at every back-trace step.                             */
+int wf_viterbi_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
+                               int32_t B, int32_t V, uint32_t flags, size_t* bytes);
+int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+               const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
+               const int32_t* seg, int32_t B, int32_t Tmax, uint32_t flags, float* best_score,
+               int32_t* best_arcs, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WF_DWFST_H_ */

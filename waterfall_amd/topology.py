@@ -1,0 +1,218 @@
+"""Token topologies of the reference, as arc lists (no OpenFst needed).
+
+Each ``_arcs_<name>`` function restates one generator script under ``/root/reference/utils`` (the
+`_k2` variants are the *training* topologies); ``build_topology`` then applies the
+symbol-table convention of the matching ``utils/prepare_<name>.sh`` (e.g. ``prepare_2state.sh:20-38``,
+``prepare_ctc.sh:20-39``): token ids = NN output columns with ``<blk>`` (or ``<SIL>``) = 0, phone ids =
+position in ``k2/phones.txt`` with ``<eps>`` = 0, arcs sorted per state by output label
+(``fstarcsort --sort_type=olabel``), then ``k2.Fsa.from_openfst(acceptor=False)`` semantics
+(``waterfall/utils/datapipe.py:168-181``): label = token, aux = phone, score = 0, one label -1 arc
+from every final state to the appended super-final state.
+
+phones: list of phone symbols in id order as in ``k2/phones.txt`` (index 0 is ``<eps>``; ``<SIL>``
+may be present and keeps its id; ``#n`` disambiguation symbols must not be present).
+"""
+from .fsa import Fsa
+
+EPS = "<eps>"
+BLK = "<blk>"
+SIL = "<SIL>"
+
+
+def _real(phones):
+    return [p for p in phones if p not in (EPS, SIL) and not p.startswith("#")]
+
+
+def _arcs_ctc(phones):
+    """utils/get_token_fst_ctc.py:25-53 (ignore_silence_between_words=True). All states final."""
+    arcs = [(0, 0, BLK, EPS)]
+    nodes = []
+    x = 1
+    for p in phones:
+        if p in (EPS, BLK, SIL):
+            continue
+        arcs += [(0, x, p, p), (x, x, p, EPS), (x, 0, BLK, EPS)]
+        nodes.append((p, x))
+        x += 1
+    for p, nid in nodes:
+        for other in range(1, len(nodes) + 1):
+            if other != nid:
+                arcs.append((other, nid, p, p))
+    return arcs, list(range(len(nodes) + 1))
+
+
+def _arcs_2state(phones):
+    """utils/get_token_fst_2state_k2.py:18-35."""
+    arcs = [(0, 0, BLK, EPS)]
+    x = 1
+    for p in _real(phones):
+        arcs += [(0, x, p + "_0", p), (x, 0, p + "_1", EPS), (x, x, p + "_0", EPS),
+                 (x, x + 1, p + "_1", EPS), (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_1", EPS)]
+        x += 2
+    return arcs, [0]
+
+
+def _arcs_2state_1(phones):
+    """utils/get_token_fst_2state-1_k2.py:18-34 (no x_0 self-loop)."""
+    arcs = [(0, 0, BLK, EPS)]
+    x = 1
+    for p in _real(phones):
+        arcs += [(0, x, p + "_0", p), (x, 0, p + "_1", EPS), (x, x + 1, p + "_1", EPS),
+                 (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_1", EPS)]
+        x += 2
+    return arcs, [0]
+
+
+def _arcs_2state_sil(phones, nsil):
+    """utils/get_token_fst_2state_k2_sil.py:19-40 (nsil=1) and ..._sil3.py:19-48 (nsil=3)."""
+    arcs = []
+    x = 1
+    for p in phones:
+        if p == EPS or p.startswith("#"):
+            continue
+        if p == SIL:
+            toks = [SIL] if nsil == 1 else [SIL + "_%d" % i for i in range(nsil)]
+            arcs += [(0, 0, t, SIL) for t in toks]
+            arcs += [(0, x, t, SIL) for t in toks]
+            arcs += [(x, x, t, EPS) for t in toks]
+            arcs += [(x, 0, t, EPS) for t in toks]
+            x += 1
+        else:
+            arcs += [(0, x, p + "_0", p), (x, 0, p + "_1", EPS), (x, x, p + "_0", EPS),
+                     (x, x + 1, p + "_1", EPS), (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_1", EPS)]
+            x += 2
+    return arcs, [0]
+
+
+def _arcs_3state_skip(phones):
+    """utils/get_token_fst_3state-skip_k2.py:18-34."""
+    arcs = [(0, 0, BLK, EPS)]
+    x = 1
+    for p in _real(phones):
+        arcs += [(0, x, p + "_0", p), (x, 0, p + "_2", EPS), (x, x + 1, p + "_1", EPS),
+                 (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_2", EPS)]
+        x += 2
+    return arcs, [0]
+
+
+def _arcs_3state_skip_1(phones):
+    """utils/get_token_fst_3state-skip-1_k2.py:18-38."""
+    arcs = [(0, 0, BLK, EPS)]
+    x = 1
+    for p in _real(phones):
+        arcs += [(0, x, p + "_0", p), (x, 0, p + "_2", EPS), (x, x + 2, p + "_2", EPS),
+                 (x + 2, x + 2, p + "_2", EPS), (x + 2, 0, p + "_2", EPS), (x, x + 1, p + "_1", EPS),
+                 (x + 1, x + 1, p + "_1", EPS), (x + 1, x + 2, p + "_2", EPS), (x + 1, 0, p + "_2", EPS)]
+        x += 3
+    return arcs, [0]
+
+
+def _arcs_3state_skip_2(phones):
+    """utils/get_token_fst_3state-skip-2_k2.py:18-39."""
+    arcs = [(0, 0, BLK, EPS)]
+    x = 1
+    for p in _real(phones):
+        arcs += [(0, x, p + "_0", p), (x, x, p + "_0", EPS), (x, x + 2, p + "_2", EPS),
+                 (x + 2, x + 2, p + "_2", EPS), (x + 2, 0, p + "_2", EPS), (x, 0, p + "_2", EPS),
+                 (x, x + 1, p + "_1", EPS), (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_2", EPS),
+                 (x + 1, x + 2, p + "_2", EPS)]
+        x += 3
+    return arcs, [0]
+
+
+def _arcs_mmictc(phones):
+    """utils/get_token_fst_mmictc_k2.py:23-54 (default mode, with <blk>)."""
+    arcs = [(0, 0, BLK, EPS)]
+    x = 1
+    for p in phones:
+        if p in (EPS, SIL) or p.startswith("#"):
+            continue
+        arcs += [(0, 0, p + "_0", p), (0, x, p + "_0", p), (x, 0, p + "_1", EPS),
+                 (x, x + 1, p + "_1", EPS), (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_1", EPS)]
+        x += 2
+    return arcs, [0]
+
+
+def _arcs_mmictc_noblk(phones):
+    """utils/get_token_fst_mmictc_k2.py:33-52 with argv[2] == 'no_blk' (<SIL> replaces <blk>)."""
+    arcs = []
+    x = 1
+    for p in phones:
+        if p == EPS or p.startswith("#"):
+            continue
+        if p == SIL:
+            arcs += [(0, 0, SIL, SIL), (0, x, SIL, SIL), (x, x, SIL, EPS), (x, 0, SIL, EPS)]
+            x += 1
+            continue
+        arcs += [(0, 0, p + "_0", p), (0, x, p + "_0", p), (x, 0, p + "_1", EPS),
+                 (x, x + 1, p + "_1", EPS), (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_1", EPS)]
+        x += 2
+    return arcs, [0]
+
+
+def _arcs_mmictc_1(phones):
+    """utils/get_token_fst_mmictc-1_k2.py:20-38."""
+    arcs = [(0, 0, BLK, EPS)]
+    x = 1
+    for p in _real(phones):
+        arcs += [(0, 0, p + "_0", p), (0, x, p + "_0", p), (x, x, p + "_0", EPS), (x, 0, p + "_1", EPS),
+                 (x, x + 1, p + "_1", EPS), (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_1", EPS)]
+        x += 2
+    return arcs, [0]
+
+
+def _tokens(phones, first, nsub):
+    """Token table of utils/prepare_<topo>.sh, k2/tokens.txt: `first` symbols then p_0..p_{nsub-1}."""
+    toks = list(first)
+    for p in _real(phones):
+        if nsub == 0:
+            toks.append(p)
+        else:
+            toks += [p + "_%d" % i for i in range(nsub)]
+    return toks
+
+
+TOPOLOGIES = {
+    # name: (arc generator, leading tokens, sub-tokens per phone)
+    "ctc": (_arcs_ctc, [BLK], 0),
+    "2state": (_arcs_2state, [BLK], 2),
+    "2state-1": (_arcs_2state_1, [BLK], 2),
+    "2state_sil": (lambda ph: _arcs_2state_sil(ph, 1), [SIL], 2),
+    "2state_sil3": (lambda ph: _arcs_2state_sil(ph, 3), [SIL + "_0", SIL + "_1", SIL + "_2"], 2),
+    "3state-skip": (_arcs_3state_skip, [BLK], 3),
+    "3state-skip-1": (_arcs_3state_skip_1, [BLK], 3),
+    "3state-skip-2": (_arcs_3state_skip_2, [BLK], 3),
+    "mmictc": (_arcs_mmictc, [BLK], 2),
+    "mmictc_noblk": (_arcs_mmictc_noblk, [SIL], 2),
+    "mmictc-1": (_arcs_mmictc_1, [BLK], 2),
+}
+
+
+def topology_text(name, phones):
+    """The OpenFst text the reference generator prints (symbolic labels), one arc per line."""
+    arcs, finals = TOPOLOGIES[name][0](phones)
+    lines = ["%d %d %s %s" % a for a in arcs] + ["%d" % f for f in finals]
+    return "\n".join(lines) + "\n"
+
+
+def build_topology(name, phones):
+    """Returns (topo: Fsa, tokens: list[str]).  len(tokens) = Lang.num_nn_output (datapipe.py:112-114)."""
+    gen, first, nsub = TOPOLOGIES[name]
+    arcs, finals = gen(phones)
+    tokens = _tokens(phones, first, nsub)
+    tok_id = {t: i for i, t in enumerate(tokens)}
+    ph_id = {p: i for i, p in enumerate(phones)}
+    rows = [(s, d, tok_id[t], ph_id[o]) for (s, d, t, o) in arcs]
+    # fstarcsort --sort_type=olabel: per state by output label (stable, then input label)
+    order = sorted(range(len(rows)), key=lambda i: (rows[i][0], rows[i][3], rows[i][2]))
+    n_states = max(max(r[0], r[1]) for r in rows) + 1
+    sf = n_states
+    out, aux = [], []
+    for i in order:
+        s, d, t, o = rows[i]
+        out.append((s, d, t, 0.0))
+        aux.append(o)
+    for f in finals:
+        out.append((f, sf, -1, 0.0))
+        aux.append(-1)
+    return Fsa.from_arcs(out, sf + 1, aux), tokens
