@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""bench.py -- DWFST loss+grad throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic log-probs already resident in
+HBM: emission gather -> concurrent alpha/beta sweeps -> posterior/gradient rows (loss + gradient
+w.r.t. log_probs, reduction 'sum'), called through the C ABI (wf_fb_logsum).  The headline workload
+is BASELINE.json configs[2] (the configuration the metric is quoted on: B=32, T=500, V=5k, CTC
+numerator graphs, "cfg3" in BASELINE.md); with N GPUs every rank processes its own B=32 batch
+(weak scaling, utterances are independent) and the step ends with ONE RCCL all-reduce of the fused
+(loss_sum, n_frames, n_infeasible) buffer.
+
+Prints one JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, measured live with HIP
+events on the launch stream), "cpu_baseline" (oracle/dwfst_oracle.c, a scalar C port of the same
+algorithm, timed on the host cores of this box on a bounded sample), "kernels", "other_workloads".
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import waterfall_amd as wf  # noqa: E402
+from waterfall_amd import _lib  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # name: (topology, P, L, kind) -- BASELINE.md section 3
+    "cfg3_ctc_bpe5k_num": dict(topo="ctc", P=5000, L=64, den=False,
+                               desc="LS BPE-5k CTC numerator (ctc_k2 path), V=5001, L=64"),
+    "cfg2_2state_char_num": dict(topo="2state", P=29, L=80, den=False,
+                                 desc="WSJ char 2state numerator, V=59, L=80"),
+    "cfg2_2state_char_den": dict(topo="2state", P=29, L=80, den=True,
+                                 desc="WSJ char 2state denominator (topology x B), V=59"),
+    "cfg4_mmictc_bpe5k_den": dict(topo="mmictc", P=5000, L=64, den=True,
+                                  desc="LS BPE-5k mmictc denominator, V=10001, S=10002, A=30002"),
+    "cfg4_3state-skip_bpe5k_num": dict(topo="3state-skip", P=5000, L=64, den=False,
+                                       desc="LS BPE-5k 3state-skip numerator, V=15001, L=64"),
+}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _np(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+class Workload:
+    """Synthetic batch (seed 777 + rank) resident on one GPU."""
+
+    def __init__(self, name, B, T, dev, seed, ragged=False):
+        w = WORKLOADS[name]
+        self.name, self.B, self.T, self.dev = name, B, T, dev
+        P, L = w["P"], w["L"]
+        rng = np.random.default_rng(seed)
+        phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
+        lazy = wf.Topology(w["topo"], phones)
+        self.V = V = lazy.num_nn_output
+        self.seqs = [[int(x) + 2 for x in rng.integers(0, P, size=L)] for _ in range(B)]
+        if w["den"]:
+            self.fsa = wf.create_fsa_vec([lazy.fsa] * B)
+        else:
+            self.fsa = wf.compile_ctc_k2_graphs(lazy, self.seqs)
+        lens = np.full(B, T)
+        if ragged:
+            lens = np.sort(rng.integers(int(0.7 * T), T + 1, size=B))[::-1].copy()
+            lens[0] = T
+        self.segs = np.stack([np.arange(B), np.zeros(B, dtype=np.int64), lens], 1).astype(np.int32)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.lp = torch.log_softmax(torch.randn(B, T, V, generator=g, device=dev) * 3.0, -1)
+        self.grad = torch.empty_like(self.lp)
+        self.tot = torch.empty(B, dtype=torch.float32, device=dev)
+        self.gscale = torch.full((B,), -1.0, dtype=torch.float32, device=dev)
+        self.gh = self.fsa.blob_host()
+        self.gd = self.fsa.blob_dev(dev)
+        n = C.c_size_t(0)
+        lib = _lib.lib()
+        _lib.check(lib.wf_fb_workspace_bytes(_np(self.gh), _np(self.fsa.utt2fsa), _np(self.segs), B, V, 0, 1, C.byref(n)))
+        self.ws_bytes = n.value
+        self.ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+        self.frames = int(lens.sum())
+        # per-utterance graph sizes for the byte / arc-update accounting
+        g2f = self.fsa.utt2fsa if self.fsa.utt2fsa is not None else np.arange(B)
+        A = np.diff(self.fsa.fsa_arc_offsets)[g2f]
+        S = self.fsa.fsa_num_states[g2f]
+        self.arc_updates = int((A * lens).sum())          # per sweep direction
+        self.S_frames = int((S * lens).sum())
+        from waterfall_amd.csrc_layout import HDR_WORDS, INFO_WORDS, INFO
+        K = np.array([self.gh[HDR_WORDS + g * INFO_WORDS + INFO["K"]] for g in g2f])
+        direct = np.array([self.gh[HDR_WORDS + g * INFO_WORDS + INFO["DIRECT"]] for g in g2f])
+        self.K_frames = int((K * lens).sum())
+        self.compact_K_frames = int((K * lens * (1 - direct)).sum())
+        self.S_mean, self.A_mean, self.K_mean = float(S.mean()), float(A.mean()), float(K.mean())
+
+    def step(self, stream):
+        lib = _lib.lib()
+        lp = self.lp
+        _lib.check(lib.wf_fb_logsum(_np(self.gh), _ptr(self.gd), _np(self.fsa.utt2fsa), _ptr(lp), lp.stride(0),
+                                    lp.stride(1), self.B, self.T, self.V, _np(self.segs), self.B, 0.0, 0,
+                                    _ptr(self.gscale), _ptr(self.tot), _ptr(self.grad), _ptr(self.ws),
+                                    self.ws_bytes, C.c_void_p(stream)))
+
+    # ---- algorithmic bytes (DESIGN.md "Kernels"): what each kernel must move, per batch --------
+    def kernel_bytes(self):
+        V = self.V
+        gather = 8 * self.compact_K_frames                      # read 4 B + write 4 B per gathered element
+        sweep = 2 * 4 * self.K_frames + 2 * 8 * self.S_frames   # emissions read by both sweeps + alpha/beta rows out
+        post = 4 * V * self.B * self.T + 2 * 8 * self.S_frames + 4 * self.K_frames  # grad rows + alpha/beta in + emissions
+        # SURVEY.md 8(d) whole-path figure: 4V (lp row) + 4V (grad row) + 8S (alpha spill + reload) per frame
+        path = (8 * V) * self.frames + 8 * self.S_frames
+        return {"gather": gather, "sweep": sweep, "post": post, "path_survey_8d": path}
+
+
+def time_steps(wl, steps, warmup, dist, stream, fused_buf):
+    def one():
+        wl.step(stream)
+        if dist is not None:
+            # single fused all-reduce: [loss_sum, n_frames, n_infeasible]
+            ok = torch.isfinite(wl.tot)
+            fused_buf[0] = -torch.where(ok, wl.tot, torch.zeros_like(wl.tot)).sum()
+            fused_buf[1] = float(wl.frames)
+            fused_buf[2] = (~ok).sum()
+            dist.all_reduce(fused_buf)
+    for _ in range(warmup):
+        one()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def kernel_times(wl, stream, reps=20):
+    """Average per-kernel duration over `reps` timed steps: HIP events recorded by the library on
+    the launch stream around each kernel."""
+    lib = _lib.lib()
+    lib.wf_timing_enable(1)
+    acc = np.zeros(3)
+    ms = (C.c_float * 3)()
+    for _ in range(reps):
+        wl.step(stream)
+        _lib.check(lib.wf_timing_read(ms))
+        acc += np.array(list(ms))
+    lib.wf_timing_enable(0)
+    return dict(zip(("gather", "sweep", "post"), (acc / reps).tolist()))
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """oracle/dwfst_oracle.c (scalar C port, fp32 accumulators as graph.py:83's default) on this
+    box's host cores, OpenMP over utterances, on the same batch; bounded to ~budget_s seconds."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    lib = C.CDLL(so)
+    from tests import util
+    graphs = wl.fsa.as_oracle_graphs()
+    lp = wl.lp.cpu().numpy()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    nthreads = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)), wl.B))
+    t0 = time.perf_counter()
+    util.c_oracle_batch(lib, graphs, lp, wl.segs, gscale=[-1.0] * wl.B, nthreads=nthreads)
+    first = time.perf_counter() - t0
+    reps = max(1, min(50, int(budget_s / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        util.c_oracle_batch(lib, graphs, lp, wl.segs, gscale=[-1.0] * wl.B, nthreads=nthreads)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"value": wl.frames / dt, "unit": "utterance-frames/s", "cores": nthreads, "kind": "port",
+           "sample": f"{reps} passes over the same batch ({wl.B}x{wl.T} frames, {wl.name}), "
+                     f"oracle/dwfst_oracle.c fp32, OpenMP over utterances; k2 itself is not installable offline",
+           "ms_per_batch": dt * 1e3}
+    if WORKLOADS[wl.name]["topo"] == "ctc" and not WORKLOADS[wl.name]["den"]:
+        # the reference's own equivalent 'builtin_ctc' loss (rnnp.py:107-108) on the same inputs
+        x = torch.from_numpy(lp).requires_grad_(True)
+        tg = torch.tensor([[p - 1 for p in s] for s in wl.seqs])
+        il = torch.from_numpy(wl.segs[:, 2].astype(np.int64))
+        tl = torch.full((wl.B,), tg.shape[1], dtype=torch.long)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 4.0:
+            x.grad = None
+            torch.nn.functional.ctc_loss(x.permute(1, 0, 2), tg, il, tl, reduction="sum").backward()
+            n += 1
+        out["torch_ctc_loss_cpu_frames_per_s"] = wl.frames * n / (time.perf_counter() - t0)
+        out["torch_threads"] = torch.get_num_threads()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg3_ctc_bpe5k_num", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--others", action="store_true", help="also time the other BASELINE workloads (N=1)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    wl = Workload(args.workload, args.batch, args.frames, dev, seed=777 + rank, ragged=args.ragged)
+    fused = torch.zeros(3, dtype=torch.float32, device=dev)
+    dt = time_steps(wl, args.steps, args.warmup, dist, stream, fused)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        tf = torch.tensor([float(wl.frames), float(wl.arc_updates)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tf)
+        total_frames, total_arcs = tf[0].item(), tf[1].item()
+    else:
+        total_frames, total_arcs = float(wl.frames), float(wl.arc_updates)
+    ms_step = dt / args.steps * 1e3
+    value = total_frames / (dt / args.steps)
+
+    out = {
+        "metric": "DWFST loss+grad utterance-frames/sec",
+        "value": value, "unit": "utterance-frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (alpha/beta accumulated in f64)", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}, B={args.batch} per GPU, "
+                               f"T={args.frames}{' ragged' if args.ragged else ''}, loss+grad, reduction=sum, exact (no output_beam pruning)",
+                   "batch_per_gpu": args.batch, "frames": args.frames, "V": wl.V,
+                   "states_per_graph": wl.S_mean, "arcs_per_graph": wl.A_mean,
+                   "parallelism": f"batch-sharded x{world}, one fused all-reduce per step" if world > 1 else "single GPU"},
+        "arc_updates_per_sec": 2 * total_arcs / (dt / args.steps),
+    }
+    if rank == 0:
+        kt = kernel_times(wl, stream)
+        kb = wl.kernel_bytes()
+        dom = max(kt, key=lambda k: kt[k])
+        ach = kb[dom] / (kt[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_launch_ms": kt[dom], "algorithmic_bytes_per_launch": kb[dom],
+                           "note": "the alpha/beta sweep is dependency-latency bound (T sequential frame steps), "
+                                   "not bandwidth bound: us_per_frame_step below is its real figure of merit"}
+        out["kernels"] = {k: {"avg_ms": kt[k], "algorithmic_bytes": kb[k],
+                              "GBps": kb[k] / (kt[k] * 1e-3) / 1e9 if kt[k] > 0 else None} for k in kt}
+        out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
+        out["path_GBps_survey_8d"] = kb["path_survey_8d"] / (ms_step * 1e-3) / 1e9
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        if args.others and world == 1:
+            others = {}
+            for name in WORKLOADS:
+                if name == args.workload:
+                    continue
+                B = 32
+                w2 = Workload(name, B, args.frames, dev, seed=777)
+                d2 = time_steps(w2, max(5, args.steps // 5), 3, None, stream, fused)
+                n2 = max(5, args.steps // 5)
+                k2 = kernel_times(w2, stream, reps=5)
+                others[name] = {"frames_per_s": w2.frames / (d2 / n2), "ms_per_step": d2 / n2 * 1e3,
+                                "arc_updates_per_sec": 2 * w2.arc_updates / (d2 / n2), "kernels_ms": k2,
+                                "desc": WORKLOADS[name]["desc"]}
+                del w2
+                torch.cuda.empty_cache()
+            out["other_workloads"] = others
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,242 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes), against the oracle.
+
+Tolerances are north_star's: total log-likelihood within 1e-4 relative, gradients within 1e-3
+absolute (fp32), Viterbi arc sequences bit-exact with ties broken by the lowest arc index.
+"""
+import numpy as np
+import pytest
+import torch
+
+import waterfall_amd as wf
+from oracle import dwfst_oracle as o
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOT_RTOL = 1e-4
+TOT_ATOL = 2e-5   # only matters for totals that are ~0 (a complete CTC denominator sums to log 1)
+GRAD_ATOL = 1e-3
+DEV = "cuda:0"
+
+TOPO_CASES = ["2state", "2state-1", "3state-skip", "3state-skip-1", "3state-skip-2", "mmictc", "mmictc-1",
+              "2state_sil", "mmictc_noblk"]
+
+
+def run_hip(fsa, lp, segs, reduction="none", target_lengths=None, use_double=False, need_grad=True):
+    x = torch.from_numpy(np.ascontiguousarray(lp)).to(DEV).requires_grad_(need_grad)
+    dense = wf.DenseFsaVec(x, torch.from_numpy(np.ascontiguousarray(segs, dtype=np.int32)))
+    loss = wf.graphloss(fsa, dense, output_beam=10, reduction=reduction, use_double_scores=use_double,
+                        target_lengths=target_lengths)
+    grad = None
+    if need_grad:
+        (loss.sum() if reduction == "none" else loss).backward()
+        grad = x.grad.cpu().numpy()
+    return loss.detach().cpu().numpy(), grad
+
+
+def check_against_oracle(c, reduction="none", use_double=False, target_lengths=None):
+    loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], reduction, target_lengths, use_double)
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, reduction,
+                              None if target_lengths is None else target_lengths.numpy())
+    np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+    return loss, grad
+
+
+@pytest.mark.parametrize("name", ["manual_ctc_ctc_small.npz", "manual_ctc_ctc_medium.npz"])
+def test_golden_ctc_from_reference_manual_ctc(name):
+    z = util.load_golden(name)
+    V = z["log_probs"].shape[-1]
+    topo, _ = wf.build_topology("ctc", util.ctc_phones(V))
+    off = z["target_off"]
+    fsa = wf.compile_ctc_k2_graphs(topo, [z["targets"][off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)])
+    B = z["log_probs"].shape[0]
+    segs = np.stack([np.arange(B), np.zeros(B), z["input_lengths"]], 1).astype(np.int32)
+    loss, grad = run_hip(fsa, z["log_probs"], segs, "none")
+    np.testing.assert_allclose(loss, z["loss_none"], rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, z["grad"], atol=GRAD_ATOL)
+    loss_sum, _ = run_hip(fsa, z["log_probs"], segs, "sum")
+    np.testing.assert_allclose(loss_sum, z["loss_sum"], rtol=TOT_RTOL, atol=TOT_ATOL)
+
+
+@pytest.mark.parametrize("topo", TOPO_CASES)
+def test_golden_topologies_from_reference_manual_ctc(topo):
+    z = util.load_golden(f"manual_ctc_{topo}.npz")
+    fsa = util.graphs_to_fsa(util.golden_graphs(z))
+    B = z["log_probs"].shape[0]
+    segs = np.stack([np.arange(B), np.zeros(B), z["input_lengths"]], 1).astype(np.int32)
+    loss, grad = run_hip(fsa, z["log_probs"], segs, "none")
+    np.testing.assert_allclose(loss, z["loss_none"], rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, z["grad"], atol=GRAD_ATOL)
+
+
+@pytest.mark.parametrize("topo", sorted(wf.TOPOLOGIES))
+@pytest.mark.parametrize("den", [False, True])
+def test_every_topology_numerator_and_denominator(topo, den):
+    if topo == "ctc" and den:
+        P = 12  # the full CTC topology is O(P^2) arcs
+    else:
+        P = 9
+    c = util.random_case(100 + len(topo), topo, B=4, T=50, L=7, P=P, den=den)
+    check_against_oracle(c)
+
+
+@pytest.mark.parametrize("reduction", ["none", "sum", "mean"])
+def test_reductions_match_graph_py(reduction):
+    c = util.random_case(7, "2state", B=5, T=30, L=4, P=6)
+    tl = torch.tensor([len(s) for s in c["seqs"]], dtype=torch.float32)
+    check_against_oracle(c, reduction, target_lengths=tl if reduction == "mean" else None)
+
+
+def test_double_scores():
+    c = util.random_case(8, "mmictc", B=3, T=40, L=5, P=6)
+    loss, grad = check_against_oracle(c, use_double=True)
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    np.testing.assert_allclose(loss, want, rtol=2e-7)
+    np.testing.assert_allclose(grad, wgrad, atol=2e-5)
+
+
+def test_no_grad_forward_only_and_shared_denominator():
+    c = util.random_case(9, "3state-skip", B=6, T=33, L=4, P=10, den=True)
+    assert c["fsa"].num_fsas == 1 and len(c["fsa"].utt2fsa) == 6   # [topo]*B stored once
+    with torch.no_grad():
+        loss, _ = run_hip(c["fsa"], c["lp"], c["segs"], "none", need_grad=False)
+    want, _ = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+
+
+def test_infeasible_utterance_gives_inf_loss_and_zero_grad():
+    # models.py:305-313 (mask_inf): an utterance shorter than its transcript has no path
+    c = util.random_case(10, "ctc", B=3, T=12, L=8, P=5, ragged=False)
+    segs = c["segs"].copy()
+    segs[1, 2] = 5    # 8 labels cannot fit in 5 frames
+    loss, grad = run_hip(c["fsa"], c["lp"], segs, "none")
+    assert np.isinf(loss[1]) and loss[1] > 0 and np.isfinite(loss[[0, 2]]).all()
+    assert np.all(grad[1] == 0) and not np.isnan(grad).any()
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], segs, None, "none")
+    np.testing.assert_allclose(loss[[0, 2]], want[[0, 2]], rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+
+
+def test_ragged_segments_start_offsets_and_unused_sequences():
+    # segments need not start at frame 0 nor cover every sequence (k2.DenseFsaVec semantics)
+    c = util.random_case(12, "2state", B=3, T=40, L=3, P=5, ragged=False)
+    lp = np.concatenate([c["lp"], c["lp"][:1]], 0)            # 4 sequences, the last one unused
+    segs = np.array([[2, 5, 30], [0, 0, 40], [1, 10, 21]], dtype=np.int32)
+    loss, grad = run_hip(c["fsa"], lp, segs, "none")
+    want, wgrad = o.graphloss(c["ographs"], lp, segs, None, "none")
+    np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+    assert np.all(grad[3] == 0) and np.all(grad[2, :5] == 0) and np.all(grad[2, 35:] == 0)
+
+
+def test_empty_transcript_and_single_frame():
+    topo, tokens = wf.build_topology("ctc", util.ctc_phones(6))
+    fsa = wf.compile_ctc_k2_graphs(topo, [[], [3], [2, 2]])
+    g = torch.Generator().manual_seed(1)
+    lp = torch.log_softmax(torch.randn(3, 4, len(tokens), generator=g), -1).numpy()
+    segs = np.array([[0, 0, 4], [1, 0, 1], [2, 0, 3]], dtype=np.int32)
+    loss, grad = run_hip(fsa, lp, segs, "none")
+    want, wgrad = o.graphloss(fsa.as_oracle_graphs(), lp, segs, None, "none")
+    np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+    np.testing.assert_allclose(loss[0], -lp[0, :, 0].sum(), rtol=1e-6)   # blanks only
+
+
+@pytest.mark.parametrize("topo,den", [("ctc", False), ("2state", False), ("mmictc", True), ("3state-skip-2", True),
+                                      ("ctc", True)])
+def test_viterbi_bit_exact(topo, den):
+    c = util.random_case(40, topo, B=4, T=60, L=8, P=8, den=den)
+    x = torch.from_numpy(c["lp"]).to(DEV)
+    dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
+    out = wf.best_path(c["fsa"], dense)
+    scores = out["scores"].cpu().numpy()
+    arcs = out["arcs"].cpu().numpy()
+    trop = wf.tot_scores(c["fsa"], dense, log_semiring=False).cpu().numpy()
+    base = c["fsa"].fsa_arc_offsets
+    for i, g in enumerate(c["ographs"]):
+        T = int(c["segs"][i, 2])
+        s, path = o.viterbi(g, c["lp"][i], T)
+        gi = 0 if c["fsa"].utt2fsa is not None else i
+        assert scores[i] == s and trop[i] == s                      # bit-exact fp32
+        assert list(arcs[i, :T + 1] - base[gi]) == path
+        assert np.all(arcs[i, T + 1:] == -1)
+        lab = [int(g["label"][a]) for a in path[:-1]]
+        assert out["labels"][i] == lab
+
+
+def test_viterbi_ties_lowest_arc_index_and_infeasible():
+    arcs = [(0, 0, 1, 0.0), (0, 0, 1, 0.0), (0, 1, 2, 0.0), (0, 1, 2, 0.0), (1, 2, -1, 0.0), (1, 2, -1, 0.0)]
+    g = o.make_graph(arcs, 3)
+    fsa = util.graphs_to_fsa([g, g])
+    lp = np.log(np.full((2, 4, 3), 1 / 3, dtype=np.float32))
+    segs = np.array([[0, 0, 4], [1, 0, 0]], dtype=np.int32)      # second utterance: T=0, needs >= 1 frame
+    dense = wf.DenseFsaVec(torch.from_numpy(lp).to(DEV), torch.from_numpy(segs))
+    out = wf.best_path(fsa, dense)
+    a = out["arcs"].cpu().numpy()
+    assert list(a[0]) == [0, 0, 0, 2, 4]
+    assert np.all(a[1] == -1) and out["scores"][1].item() == -np.inf
+
+
+def test_tot_scores_log_and_double():
+    c = util.random_case(41, "2state", B=3, T=45, L=5, P=7)
+    dense = wf.DenseFsaVec(torch.from_numpy(c["lp"]).to(DEV), torch.from_numpy(c["segs"]))
+    want, _ = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    t32 = wf.tot_scores(c["fsa"], dense, True, False).cpu().numpy()
+    t64 = wf.tot_scores(c["fsa"], dense, True, True).cpu().numpy()
+    np.testing.assert_allclose(-t32, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(-t64, want, rtol=1e-6)
+    assert t64.dtype == np.float64
+    v64 = wf.tot_scores(c["fsa"], dense, False, True).cpu().numpy()
+    for i, g in enumerate(c["ographs"]):
+        s, _ = o.viterbi(g, c["lp"][i], int(c["segs"][i, 2]), dtype=np.float64)
+        np.testing.assert_allclose(v64[i], s, rtol=1e-12)
+
+
+def test_non_contiguous_log_probs_view():
+    # encoder output sliced along V (stride(1) != V): strides travel through the ABI
+    c = util.random_case(13, "ctc", B=2, T=20, L=3, P=4, ragged=False)
+    V = c["V"]
+    big = torch.zeros(2, 20, V + 3)
+    big[:, :, :V] = torch.from_numpy(c["lp"])
+    x = big.to(DEV)[:, :, :V].requires_grad_(True)
+    dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
+    loss = wf.graphloss(c["fsa"], dense, reduction="sum")
+    loss.backward()
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "sum")
+    np.testing.assert_allclose(loss.item(), want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), wgrad, atol=GRAD_ATOL)
+
+
+# ---- BASELINE.json sizes: C oracle where it finishes in seconds + size-independent properties ----
+
+def _full_size(topo, P, L, den, seed=777, B=32, T=500):
+    return util.random_case(seed, topo, B=B, T=T, L=L, P=P, den=den, ragged=True)
+
+
+@pytest.mark.parametrize("topo,P,L,den", [("2state", 29, 80, False), ("2state", 29, 80, True),
+                                          ("ctc", 5000, 64, False)])
+def test_full_size_against_c_oracle_and_properties(oracle_lib, topo, P, L, den):
+    c = _full_size(topo, P, L, den)
+    loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
+    B = len(loss)
+    tot_d, grad_d = util.c_oracle_batch(oracle_lib, c["ographs"], c["lp"], c["segs"], gscale=[-1.0] * B,
+                                        use_double=True, nthreads=8)
+    np.testing.assert_allclose(loss, -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, grad_d, atol=GRAD_ATOL)
+    for b in range(B):
+        T = int(c["segs"][b, 2])
+        np.testing.assert_allclose(grad[b, :T].sum(-1), -1.0, atol=2e-3)   # posteriors of one frame sum to 1
+        assert np.all(grad[b, T:] == 0)
+    assert np.all(grad <= 0)
+
+
+def test_full_size_mmictc_denominator_properties():
+    # cfg4 (LS BPE-5k mmictc denominator: S=10002, A=30002, fan-in(0)=15001) at reduced batch so the
+    # test stays short; checked through properties + a float64 C-oracle pass on two utterances
+    c = util.random_case(777, "mmictc", B=4, T=120, L=8, P=5000, den=True)
+    loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
+    for b in range(4):
+        T = int(c["segs"][b, 2])
+        np.testing.assert_allclose(grad[b, :T].sum(-1), -1.0, atol=2e-3)
+        assert np.all(grad[b, T:] == 0)

@@ -1,0 +1,172 @@
+"""CPU tests of the host layer: topologies vs the reference generators' output, the numerator graph
+compiler vs the oracle, graph preparation, and the C ABI surface (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import waterfall_amd as wf
+from waterfall_amd import _lib
+from oracle import graphs as og
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", sorted(wf.TOPOLOGIES))
+def test_topology_text_equals_reference_generator_output(name):
+    # tests/golden/topo_<name>.txt is the stdout of the reference's utils/get_token_fst_*_k2.py
+    want = open(os.path.join(util.GOLDEN, f"topo_{name}.txt")).read().split("\n")
+    got = wf.topology_text(name, util.PHONES).split("\n")
+    norm = lambda ls: [" ".join(l.split()) for l in ls if l.strip()]
+    assert norm(got) == norm(want)
+
+
+@pytest.mark.parametrize("name,S,A", [("ctc", lambda P: 1 + P, lambda P: 1 + 3 * P + P * (P - 1)),
+                                      ("2state", lambda P: 1 + 2 * P, lambda P: 1 + 6 * P),
+                                      ("2state-1", lambda P: 1 + 2 * P, lambda P: 1 + 5 * P),
+                                      ("3state-skip", lambda P: 1 + 2 * P, lambda P: 1 + 5 * P),
+                                      ("3state-skip-1", lambda P: 1 + 3 * P, lambda P: 1 + 9 * P),
+                                      ("3state-skip-2", lambda P: 1 + 3 * P, lambda P: 1 + 10 * P),
+                                      ("mmictc", lambda P: 1 + 2 * P, lambda P: 1 + 6 * P),
+                                      ("mmictc-1", lambda P: 1 + 2 * P, lambda P: 1 + 7 * P)])
+def test_topology_sizes_match_survey_table(name, S, A):
+    P = 29
+    phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
+    topo, tokens = wf.build_topology(name, phones)
+    nfinal = (1 + P) if name == "ctc" else 1
+    assert topo.fsa_num_states[0] == S(P) + 1            # + super-final
+    assert topo.num_arcs == A(P) + nfinal                # + label -1 arcs
+    assert topo.labels.max() == len(tokens) - 1 and set(topo.labels[topo.labels >= 0]) == set(range(len(tokens)))
+
+
+def test_from_openfst_matches_oracle_parser():
+    txt = "0 1 1 5 0.5\n1 1 2 0\n1 0.25\n0 0 3 0 1.5\n"
+    f = wf.Fsa.from_openfst(txt, acceptor=False)
+    g = og.from_openfst_text(txt)
+    h = f.as_oracle_graphs()[0]
+    for k in ("src", "dst", "label", "aux", "score"):
+        assert np.array_equal(g[k], h[k]), k
+    assert h["num_states"] == 3 and list(h["label"]) == [1, 3, 2, -1]
+    assert list(h["score"]) == [-0.5, -1.5, 0.0, -0.25]
+
+
+@pytest.mark.parametrize("name", sorted(wf.TOPOLOGIES))
+def test_compose_matches_oracle_compose(name):
+    topo, tokens = wf.build_topology(name, util.PHONES)
+    tg = topo.as_oracle_graphs()[0]
+    sil = "sil" in name or "noblk" in name
+    seqs = [[2, 2, 3], [6], [4, 5, 6, 2, 2, 2, 3]]
+    if sil:
+        seqs = [[1] + s + [1] for s in seqs]
+    vec = wf.compile_ctc_k2_graphs(topo, seqs)
+    for got, seq in zip(vec.as_oracle_graphs(), seqs):
+        want = og.compose_topo_transcript(tg, seq)
+        assert got["num_states"] == want["num_states"]
+        for k in ("src", "dst", "label", "aux", "score"):
+            assert np.array_equal(got[k], want[k]), (name, k)
+
+
+def test_compose_empty_transcript_and_ctc_sizes():
+    topo, _ = wf.build_topology("ctc", util.ctc_phones(12))
+    vec = wf.compile_ctc_k2_graphs(topo, [[], [3, 3], list(range(1, 11))])
+    S = vec.fsa_num_states
+    assert S[0] == 2            # only (0,0) + super-final: accepts blanks only
+    # ctc numerators S ~ 2L+2
+    assert S[1] == 2 * 2 + 2 and S[2] == 2 * 10 + 2
+
+
+def test_prepared_blob_is_consistent():
+    from waterfall_amd.csrc_layout import INFO, HDR_WORDS, INFO_WORDS
+    c = util.random_case(1, "mmictc", B=2, T=5, L=3, P=20)
+    for fsa in (c["fsa"], wf.create_fsa_vec([c["topo"]] * 2)):
+        b = fsa.blob_host()
+        for g in range(fsa.num_fsas):
+            I = b[HDR_WORDS + g * INFO_WORDS: HDR_WORDS + (g + 1) * INFO_WORDS]
+            S, A, K = I[INFO["S"]], I[INFO["A"]], I[INFO["K"]]
+            arcs = fsa.arcs[fsa.fsa_arc_offsets[g]:fsa.fsa_arc_offsets[g + 1]]
+            em = arcs[arcs[:, 2] >= 0]
+            assert A == len(em) and S == fsa.fsa_num_states[g]
+            in_off = b[I[INFO["IN_OFF"]]: I[INFO["IN_OFF"]] + S + 1]
+            in_src = b[I[INFO["IN_SRC"]]: I[INFO["IN_SRC"]] + A]
+            in_arc = b[I[INFO["IN_ARC"]]: I[INFO["IN_ARC"]] + A]
+            assert in_off[0] == 0 and in_off[-1] == A and np.all(np.diff(in_off) >= 0)
+            for s in range(S):
+                ids = in_arc[in_off[s]:in_off[s + 1]]
+                assert np.all(arcs[ids, 1] == s) and np.all(np.diff(ids) > 0)
+                assert np.array_equal(arcs[ids, 0], in_src[in_off[s]:in_off[s + 1]])
+            lab_off = b[I[INFO["LAB_OFF"]]: I[INFO["LAB_OFF"]] + K + 1]
+            assert lab_off[-1] == A
+            labels = b[I[INFO["LABELS"]]: I[INFO["LABELS"]] + K]
+            if I[INFO["DIRECT"]]:
+                assert K == em[:, 2].max() + 1
+            else:
+                assert np.array_equal(labels, np.unique(em[:, 2]))
+            nh = I[INFO["NHEAVY_IN"]]
+            heavy = set(b[I[INFO["HEAVY_IN"]]: I[INFO["HEAVY_IN"]] + nh].tolist())
+            assert heavy == set(np.nonzero(np.diff(in_off) > 16)[0].tolist())
+
+
+def test_graph_validation_errors():
+    bad = wf.Fsa(np.array([[0, 5, 1, 0]], dtype=np.int32), None, [0, 1], [2])
+    with pytest.raises(_lib.WfError, match="state out of range"):
+        bad.blob_host()
+    bad = wf.Fsa(np.array([[0, 1, 1, 0]], dtype=np.int32), None, [0, 1], [2])
+    with pytest.raises(_lib.WfError, match="only label -1 arcs may enter the final state"):
+        bad.blob_host()
+    bad = wf.Fsa(np.array([[0, 0, -1, 0]], dtype=np.int32), None, [0, 1], [2])
+    with pytest.raises(_lib.WfError, match="must enter the final state"):
+        bad.blob_host()
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "wf_dwfst.h")).read()
+    declared = set(re.findall(r"\b(wf_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"wf_graph_host"}
+    lib = _lib.lib()
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.wf_version() >= 1
+    # error path through the ABI: null graph -> WF_EINVAL + message, no exception
+    n = C.c_size_t(0)
+    assert lib.wf_graph_prepare_bytes(None, C.byref(n)) == -1
+    assert b"null" in lib.wf_last_error()
+
+
+def test_no_cpu_fallback_in_product():
+    # the product must not import the oracle, and compute calls must refuse CPU tensors
+    import torch
+    src = ""
+    for fn in os.listdir(os.path.join(ROOT, "waterfall_amd")):
+        if fn.endswith(".py"):
+            src += open(os.path.join(ROOT, "waterfall_amd", fn)).read()
+    assert "import oracle" not in src and "from oracle" not in src
+    c = util.random_case(2, "ctc", B=2, T=6, L=2, P=3)
+    dense = wf.DenseFsaVec(torch.from_numpy(c["lp"]), torch.from_numpy(c["segs"]))
+    with pytest.raises(_lib.WfError, match="no CPU path"):
+        wf.graphloss(c["fsa"], dense)
+
+
+@pytest.mark.parametrize("name", sorted(wf.TOPOLOGIES))
+def test_lazy_restricted_topology_composes_to_the_same_graph(name):
+    phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(12)]
+    lazy = wf.Topology(name, phones)
+    sil = "sil" in name or "noblk" in name
+    seqs = [[5, 5, 9, 2], [13], [3, 8, 3, 8, 3]]
+    if sil:
+        seqs = [[1] + s + [1] for s in seqs]
+    a = wf.compile_ctc_k2_graphs(lazy.fsa, seqs)
+    b = wf.compile_ctc_k2_graphs(lazy, seqs)
+    assert np.array_equal(a.arcs, b.arcs) and np.array_equal(a.aux_labels, b.aux_labels)
+    assert np.array_equal(a.fsa_num_states, b.fsa_num_states)
+
+
+def test_layout_mirror_in_sync_with_header():
+    import re
+    from waterfall_amd import csrc_layout as L
+    h = open(os.path.join(ROOT, "waterfall_amd", "csrc", "wf_internal.h")).read()
+    assert {k: int(v) for k, v in re.findall(r"WF_I_([A-Z_]+) = (\d+)", h)} == L.INFO
+    assert int(re.search(r"#define WF_INFO_WORDS (\d+)", h).group(1)) == L.INFO_WORDS

@@ -15,6 +15,7 @@ import numpy as np
 
 from . import _lib
 from .fsa import Fsa
+from .topology import Topology
 
 
 class LinearFsaVec:
@@ -52,6 +53,8 @@ def arc_sort(fsa):
 def compose(topo, b, treat_epsilons_specially=False):
     """k2.compose(topo, linear_with_self_loops, treat_epsilons_specially=False) (models.py:269-270).
 
+    topo: the topology Fsa, or a lazy ``Topology`` (restricted per transcript: identical result,
+    needed for the O(P^2) CTC topology at large P).
     Product states (q, i), numbered in BFS order from (0, 0); topology arc (q -> q', tok : ph) gives
     (q,i) -> (q',i) if ph == 0 and (q,i) -> (q',i+1) if ph == b[i]; final arcs from (q, L) when q is
     final.  Output labels = tokens, aux_labels = phones.
@@ -60,13 +63,16 @@ def compose(topo, b, treat_epsilons_specially=False):
         raise NotImplementedError("the reference always composes with treat_epsilons_specially=False")
     if not isinstance(b, LinearFsaVec) or not b.self_loops:
         raise TypeError("compose expects remove_epsilon_and_add_self_loops(linear_fsa(...)) on the right")
-    assert topo.num_fsas == 1 and topo.utt2fsa is None, "topology must be a single FSA"
+    lazy = isinstance(topo, Topology)
+    if not lazy:
+        assert topo.num_fsas == 1 and topo.utt2fsa is None, "topology must be a single FSA"
     lib = _lib.lib()
-    ta = topo.arcs
-    tx = topo.aux_labels
-    nA, nS = ta.shape[0], int(topo.fsa_num_states[0])
     arcs_l, aux_l, off, ns = [], [], [0], []
     for seq in b.seqs:
+        t = topo.restricted(seq) if lazy else topo
+        ta = t.arcs
+        tx = t.aux_labels
+        nA, nS = ta.shape[0], int(t.fsa_num_states[0])
         na, nst = C.c_int32(0), C.c_int32(0)
         cap = max(64, 8 * (len(seq) + 2))
         while True:

@@ -45,7 +45,7 @@ constexpr int kMaxThreads = 1024;
 constexpr int kPF = 8;        // emission prefetch registers per thread
 constexpr int kMaxChunk = 32; // frames per emission chunk
 constexpr int kMaxHeavy = 16; // heavy states reduced per cooperative round
-constexpr size_t kLdsBudget = 150 * 1024;
+constexpr size_t kLdsBudget = 160 * 1024;  // one workgroup may own the CU's whole LDS (MI355X: 160 KiB)
 
 enum SweepMode { M_FB = 0, M_TOT_LOG = 1, M_TOT_MAX = 2, M_VITERBI = 3 };
 
@@ -59,21 +59,25 @@ __device__ __forceinline__ double flog(double x) { return log(x); }
 
 template <typename Acc> __device__ __forceinline__ Acc neg_inf() { return (Acc)(-INFINITY); }
 
-// running log-sum-exp state (m = running max, s = sum of exp(v - m))
-template <typename Acc> __device__ __forceinline__ void lse_push(Acc& m, Acc& s, Acc v) {
-    Acc d = (v == neg_inf<Acc>()) ? neg_inf<Acc>() : v - m;  // m == -inf, v finite -> +inf
-    Acc e = fexp(-fabs(d));
-    s = d > 0 ? s * e + (Acc)1 : s + e;
+// running log-sum-exp state: m = running max (Acc), s = sum of exp(v - m) (Sum).
+// Acc = double, Sum = float is the default log-semiring arithmetic: alpha/beta and every max are
+// kept in fp64, only the *differences* v - m (small numbers) go through the fp32 v_exp/v_log units.
+// Plain fp32 alpha (what k2 does with use_double_scores=False) drifts by ~3e-3 in the posterior
+// exponent over T = 500 frames, which breaks the 1e-3 gradient tolerance.
+template <typename Acc, typename Sum> __device__ __forceinline__ void lse_push(Acc& m, Sum& s, Acc v) {
+    Sum d = (v == neg_inf<Acc>()) ? neg_inf<Sum>() : (Sum)(v - m);  // m == -inf, v finite -> +inf
+    Sum e = fexp(-fabs(d));
+    s = d > 0 ? s * e + (Sum)1 : s + e;
     m = fmax(m, v);
 }
-template <typename Acc> __device__ __forceinline__ void lse_merge(Acc& m, Acc& s, Acc m2, Acc s2) {
+template <typename Acc, typename Sum> __device__ __forceinline__ void lse_merge(Acc& m, Sum& s, Acc m2, Sum s2) {
     Acc mn = fmax(m, m2);
     if (mn == neg_inf<Acc>()) { m = mn; s = 0; return; }
-    s = s * fexp(m - mn) + s2 * fexp(m2 - mn);
+    s = s * fexp((Sum)(m - mn)) + s2 * fexp((Sum)(m2 - mn));
     m = mn;
 }
-template <typename Acc> __device__ __forceinline__ Acc lse_value(Acc m, Acc s) {
-    return (m == neg_inf<Acc>()) ? m : m + flog(s);
+template <typename Acc, typename Sum> __device__ __forceinline__ Acc lse_value(Acc m, Sum s) {
+    return (m == neg_inf<Acc>()) ? m : m + (Acc)flog(s);
 }
 // tropical: (value, arc) with ties -> lowest arc index
 template <typename Acc> __device__ __forceinline__ void max_push(Acc& m, int& arc, Acc v, int a) {
@@ -91,12 +95,14 @@ struct SweepArgs {
     void* alpha;   // arena of Acc
     void* beta;
     void* tot;     // float[B] (double[B] for tot-only + double acc)
+    double* totd;  // workspace copy of tot in fp64 for post_kernel (M_FB), may be null
     int32_t* bp;   // viterbi back-pointers, arena int32: [utt](T x S)
     int32_t* fin_arc;  // viterbi: best final arc per utterance [B]
     int chunk;     // frames per emission chunk (ESTAGE)
     int kpad;      // LDS emission row pitch
     int smax;      // LDS alpha pitch (max states)
     int arcs_lds_words;  // words reserved for the LDS copy of the CSR arrays
+    int hcap;      // heavy states reduced per cooperative round (sizes the LDS reduction scratch)
     int tot_double;
 };
 
@@ -128,20 +134,21 @@ struct ArcsGlobal {
 
 // One frame step over the states owned by this thread + cooperative heavy states.
 // cur/nxt: LDS alpha buffers; erow(col) returns the emission of column col for this frame.
-template <typename Acc, bool TROP, typename Arcs, typename ERow>
+template <typename Acc, typename Sum, bool TROP, typename Arcs, typename ERow>
 __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, const Acc* cur, Acc* nxt,
-                                           int S, int nheavy, const int32_t* heavy, Acc* red,
+                                           int S, int nheavy, int hcap, const int32_t* heavy, Acc* red,
                                            int* red_arc, const int32_t* arc_id, int32_t* bp_row,
                                            Acc* store_row) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     // ---- heavy states: every thread takes a strided slice of the arc list
-    for (int h0 = 0; h0 < nheavy; h0 += kMaxHeavy) {
-        const int hn = min(kMaxHeavy, nheavy - h0);
+    for (int h0 = 0; h0 < nheavy; h0 += hcap) {
+        const int hn = min(hcap, nheavy - h0);
         for (int hi = 0; hi < hn; ++hi) {
             const int h = heavy[h0 + hi];
             const int a0 = arcs.begin(h), a1 = arcs.begin(h + 1);
-            Acc m = neg_inf<Acc>(), s = 0;
+            Acc m = neg_inf<Acc>();
+            Sum s = 0;
             int barc = 0x7fffffff;
             for (int a = a0 + tid; a < a1; a += nt) {
                 int oth, col; float w;
@@ -154,20 +161,22 @@ __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, c
             for (int o = 32; o > 0; o >>= 1) {
                 Acc m2 = shfl_xor(m, o);
                 if (TROP) { int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
-                else { Acc s2 = shfl_xor(s, o); lse_merge(m, s, m2, s2); }
+                else { Sum s2 = shfl_xor(s, o); lse_merge(m, s, m2, s2); }
             }
             if (lane == 0) {
                 red[(hi * 16 + wave) * 2] = m;
-                red[(hi * 16 + wave) * 2 + 1] = s;
+                red[(hi * 16 + wave) * 2 + 1] = (Acc)s;
                 if (TROP) red_arc[hi * 16 + wave] = barc;
             }
         }
         __syncthreads();
         if (tid < hn) {
-            Acc m = red[(tid * 16) * 2], s = red[(tid * 16) * 2 + 1];
+            Acc m = red[(tid * 16) * 2];
+            Sum s = (Sum)red[(tid * 16) * 2 + 1];
             int barc = TROP ? red_arc[tid * 16] : 0;
             for (int w = 1; w < nw; ++w) {
-                Acc m2 = red[(tid * 16 + w) * 2], s2 = red[(tid * 16 + w) * 2 + 1];
+                Acc m2 = red[(tid * 16 + w) * 2];
+                Sum s2 = (Sum)red[(tid * 16 + w) * 2 + 1];
                 if (TROP) max_push(m, barc, m2, red_arc[tid * 16 + w]);
                 else lse_merge(m, s, m2, s2);
             }
@@ -177,13 +186,14 @@ __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, c
             if (store_row) store_row[h] = val;
             if (TROP && bp_row) bp_row[h] = (m == neg_inf<Acc>()) ? -1 : barc;
         }
-        if (h0 + kMaxHeavy < nheavy) __syncthreads();
+        if (h0 + hcap < nheavy) __syncthreads();
     }
     // ---- ordinary states: one lane per state
     for (int sidx = tid; sidx < S; sidx += nt) {
         const int a0 = arcs.begin(sidx), a1 = arcs.begin(sidx + 1);
         if (a1 - a0 > WF_HEAVY_DEG) continue;
-        Acc m = neg_inf<Acc>(), s = 0;
+        Acc m = neg_inf<Acc>();
+        Sum s = 0;
         int barc = 0x7fffffff;
         for (int a = a0; a < a1; ++a) {
             int oth, col; float w;
@@ -208,7 +218,7 @@ struct ERowGlobal {
     __device__ __forceinline__ float operator()(int col) const { return p[col]; }
 };
 
-template <typename Acc, int MODE, bool ARCS_LDS, bool ESTAGE>
+template <typename Acc, typename Sum, int MODE, bool ARCS_LDS, bool ESTAGE>
 __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool TROP = (MODE == M_TOT_MAX || MODE == M_VITERBI);
@@ -225,9 +235,9 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
     // ---- LDS carve-up
     Acc* buf0 = (Acc*)smem;
     Acc* buf1 = buf0 + p.smax;
-    Acc* red = buf1 + p.smax;                         // [kMaxHeavy][16][2]
-    int* red_arc = (int*)(red + kMaxHeavy * 16 * 2);  // [kMaxHeavy][16]
-    float* ebuf = (float*)(red_arc + kMaxHeavy * 16); // [2][chunk*kpad]
+    Acc* red = buf1 + p.smax;                       // [hcap][16][2]
+    int* red_arc = (int*)(red + p.hcap * 16 * 2);   // [hcap][16]
+    float* ebuf = (float*)(red_arc + p.hcap * 16);  // [2][chunk*kpad]
     int32_t* larcs = (int32_t*)(ebuf + (ESTAGE ? 2 * p.chunk * p.kpad : 0));
 
     const int32_t* g_off = blob + I[dir ? WF_I_OUT_OFF : WF_I_IN_OFF];
@@ -318,20 +328,20 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
                 if (ARCS_LDS) {
                     ArcsLds arcs{larcs, larcs + ((S + 1 + 3) & ~3),
                                  (const float*)(larcs + ((S + 1 + 3) & ~3) + ((A + 3) & ~3))};
-                    sweep_step<Acc, TROP>(arcs, er, cur, nxt, S, nheavy, heavy, red, red_arc, arc_id, bp_row, store_row);
+                    sweep_step<Acc, Sum, TROP>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row);
                 } else {
                     ArcsGlobal arcs{g_off, g_oth, g_col, g_w};
-                    sweep_step<Acc, TROP>(arcs, er, cur, nxt, S, nheavy, heavy, red, red_arc, arc_id, bp_row, store_row);
+                    sweep_step<Acc, Sum, TROP>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row);
                 }
             } else {
                 ERowGlobal er{ebase + (int64_t)f * epitch};
                 if (ARCS_LDS) {
                     ArcsLds arcs{larcs, larcs + ((S + 1 + 3) & ~3),
                                  (const float*)(larcs + ((S + 1 + 3) & ~3) + ((A + 3) & ~3))};
-                    sweep_step<Acc, TROP>(arcs, er, cur, nxt, S, nheavy, heavy, red, red_arc, arc_id, bp_row, store_row);
+                    sweep_step<Acc, Sum, TROP>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row);
                 } else {
                     ArcsGlobal arcs{g_off, g_oth, g_col, g_w};
-                    sweep_step<Acc, TROP>(arcs, er, cur, nxt, S, nheavy, heavy, red, red_arc, arc_id, bp_row, store_row);
+                    sweep_step<Acc, Sum, TROP>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row);
                 }
             }
             if (step + 1 == step_end && c + 1 < nchunks) commit_chunk(c + 1);
@@ -346,7 +356,8 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
         const int32_t* fsrc = blob + I[WF_I_FIN_SRC];
         const float* fw = (const float*)(blob + I[WF_I_FIN_W]);
         const int32_t* farc = blob + I[WF_I_FIN_ARC];
-        Acc m = neg_inf<Acc>(), s = 0;
+        Acc m = neg_inf<Acc>();
+        Sum s = 0;
         int barc = 0x7fffffff;
         for (int i = tid; i < NF; i += nt) {
             Acc v = cur[fsrc[i]] + (Acc)fw[i];
@@ -357,19 +368,20 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
         for (int o = 32; o > 0; o >>= 1) {
             Acc m2 = shfl_xor(m, o);
             if (TROP) { int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
-            else { Acc s2 = shfl_xor(s, o); lse_merge(m, s, m2, s2); }
+            else { Sum s2 = shfl_xor(s, o); lse_merge(m, s, m2, s2); }
         }
         const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-        if (lane == 0) { red[wave * 2] = m; red[wave * 2 + 1] = s; if (TROP) red_arc[wave] = barc; }
+        if (lane == 0) { red[wave * 2] = m; red[wave * 2 + 1] = (Acc)s; if (TROP) red_arc[wave] = barc; }
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < nw; ++w) {
                 if (TROP) max_push(m, barc, red[w * 2], red_arc[w]);
-                else lse_merge(m, s, red[w * 2], red[w * 2 + 1]);
+                else lse_merge(m, s, red[w * 2], (Sum)red[w * 2 + 1]);
             }
             Acc val = TROP ? m : lse_value(m, s);
             if (p.tot_double) ((double*)p.tot)[u] = (double)val;
             else ((float*)p.tot)[u] = (float)val;
+            if (MODE == M_FB && p.totd) p.totd[u] = (double)val;
             if (MODE == M_VITERBI) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
         }
     }
@@ -415,18 +427,18 @@ struct PostArgs {
     const float* lp;
     int64_t strideB, strideT;
     const float* E;
-    const void* alpha;
-    const void* beta;
-    const float* tot;
+    const double* alpha;
+    const double* beta;
+    const double* totd;
     float* grad;
     int Tmax, V, smax;
 };
 
-template <typename Acc>
 __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float* la = (float*)smem;   // alpha_t - tot
-    float* lb = la + p.smax;    // beta_{t+1}
+    __shared__ double wmax[4];
+    float* la = (float*)smem;   // alpha_t[s] - a_ref
+    float* lb = la + p.smax;    // beta_{t+1}[s] - (tot - a_ref)
     const int tid = threadIdx.x, nt = blockDim.x;
     const int f = blockIdx.x, q = blockIdx.y;
     float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
@@ -436,19 +448,28 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     const int64_t* U = p.utt + (int64_t)(live ? u : 0) * WF_U_WORDS;
     const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
     const int t = f - start;
-    float tot = live ? p.tot[u] : 0.f;
-    live = live && t >= 0 && t < T && tot != -INFINITY;
+    const double tot = live ? p.totd[u] : 0.0;
+    live = live && t >= 0 && t < T && tot != (double)-INFINITY;
     if (!live) {
         for (int v = tid; v < V; v += nt) grow[v] = 0.f;
         return;
     }
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
     const int S = I[WF_I_S], K = I[WF_I_K], direct = I[WF_I_DIRECT];
-    const Acc* arow = (const Acc*)p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
-    const Acc* brow = (const Acc*)p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    // reference point: the best alpha of this frame, so that both LDS vectors hold small numbers
+    double mx = (double)-INFINITY;
+    for (int s = tid; s < S; s += nt) mx = fmax(mx, arow[s]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, shfl_xor(mx, o));
+    if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+    __syncthreads();
+    const double a_ref = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    const double b_ref = tot - a_ref;
     for (int s = tid; s < S; s += nt) {
-        la[s] = (float)(arow[s] - (Acc)tot);
-        lb[s] = (float)brow[s];
+        la[s] = (float)(arow[s] - a_ref);
+        lb[s] = (float)(brow[s] - b_ref);
     }
     const int32_t* loff = p.blob + I[WF_I_LAB_OFF];
     const int32_t* lsrc = p.blob + I[WF_I_LAB_SRC];
@@ -517,10 +538,10 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
     int B = 0;
-    size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_E = 0, off_alpha = 0, off_beta = 0,
+    size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_totd = 0, off_E = 0, off_alpha = 0, off_beta = 0,
            off_bp = 0, off_finarc = 0, total = 0;
     std::vector<int64_t> utt;  // B * WF_U_WORDS
-    int smax = 0, kmax_compact = 0, kmax = 0, amax = 0;
+    int smax = 0, kmax_compact = 0, kmax = 0, amax = 0, hmax = 0;
     bool any_compact = false, any_heavy = false, arcs_lds_ok = true;
     int64_t n_E = 0, n_ab = 0;
     int Tlong = 0;
@@ -562,6 +583,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         P->amax = std::max(P->amax, (int)I[WF_I_A]);
         P->Tlong = std::max(P->Tlong, T);
         if (I[WF_I_NHEAVY_IN] || I[WF_I_NHEAVY_OUT]) P->any_heavy = true;
+        P->hmax = std::max(P->hmax, std::max((int)I[WF_I_NHEAVY_IN], (int)I[WF_I_NHEAVY_OUT]));
         if (I[WF_I_S] > 65535 || I[WF_I_K] > 65535) P->arcs_lds_ok = false;
         row0 += T;
     }
@@ -571,6 +593,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     P->off_seq2utt = o; o = align_up(o + sizeof(int32_t) * std::max(num_seqs, 1), 256);
     P->off_gscale = o; o = align_up(o + sizeof(float) * B, 256);
     P->off_finarc = o; o = align_up(o + sizeof(int32_t) * B, 256);
+    P->off_totd = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
     if (mode == 0) {
         P->off_alpha = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
@@ -582,8 +605,27 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     return WF_OK;
 }
 
+// optional per-kernel timing (bench.py's roofline leg): HIP events recorded on the caller's stream
+// around each kernel of the last wf_fb_logsum / wf_fb_backward call of this thread.
+struct Timing {
+    bool on = false;
+    hipEvent_t ev[5] = {};   // t0 | gather | sweep | (post t0) | post
+    bool made = false;
+    bool have_fwd = false, have_post = false;
+};
+thread_local Timing g_tm;
+int tm_record(int i, hipStream_t st) {
+    if (!g_tm.on) return WF_OK;
+    if (!g_tm.made) {
+        for (auto& e : g_tm.ev) HIP_TRY(hipEventCreate(&e));
+        g_tm.made = true;
+    }
+    HIP_TRY(hipEventRecord(g_tm.ev[i], st));
+    return WF_OK;
+}
+
 struct SweepCfg {
-    int threads, chunk, kpad, smax, arcs_words;
+    int threads, chunk, kpad, smax, arcs_words, hcap;
     bool arcs_lds, estage;
     size_t lds;
 };
@@ -592,7 +634,8 @@ SweepCfg sweep_config(const Plan& P, size_t acc_bytes) {
     SweepCfg c{};
     c.threads = std::min(kMaxThreads, std::max(64, (int)align_up(P.smax, 64)));
     c.smax = (int)align_up(P.smax, 4);
-    size_t base = 2 * (size_t)c.smax * acc_bytes + kMaxHeavy * 16 * 2 * acc_bytes + kMaxHeavy * 16 * 4;
+    c.hcap = std::max(1, std::min(kMaxHeavy, P.hmax));
+    size_t base = 2 * (size_t)c.smax * acc_bytes + (size_t)c.hcap * 16 * 2 * acc_bytes + (size_t)c.hcap * 16 * 4;
     // emission staging
     const int kmax = std::max(P.kmax, 1);
     c.kpad = kmax;
@@ -611,13 +654,16 @@ SweepCfg sweep_config(const Plan& P, size_t acc_bytes) {
     return c;
 }
 
-template <typename Acc, int MODE>
+template <typename Acc, typename Sum, int MODE>
 int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
     const int ndir = (MODE == M_FB) ? 2 : 1;
     dim3 grid(B * ndir), block(c.threads);
+    if (c.lds > kLdsBudget)
+        return wf_fail(WF_EUNSUPPORTED, "graph too large for the LDS-resident sweep: %d states need %zu B of LDS (> %zu)",
+                       c.smax, c.lds, kLdsBudget);
 #define WF_LAUNCH(AL, ES)                                                                            \
     do {                                                                                             \
-        auto k = sweep_kernel<Acc, MODE, AL, ES>;                                                    \
+        auto k = sweep_kernel<Acc, Sum, MODE, AL, ES>;                                                    \
         if (c.lds > 48 * 1024)                                                                       \
             HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds)); \
         hipLaunchKernelGGL(k, grid, block, c.lds, st, a);                                            \
@@ -637,7 +683,7 @@ extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2
                                      int32_t B, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes) {
     if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
     Plan P;
-    const size_t ab = (flags & WF_DOUBLE_ACC) ? 8 : 4;
+    const size_t ab = 8;  // log semiring: alpha/beta are always kept in fp64
     int maxseq = 0;
     if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
     int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, (need_grad || (flags & WF_KEEP_AB)) ? 0 : 1, &P);
@@ -676,31 +722,6 @@ int build_seq2utt(const int32_t* seg, int B, int num_seqs, std::vector<int32_t>*
     return WF_OK;
 }
 
-int launch_post(const Plan& P, bool dbl, const void* graph_dev, unsigned char* ws, const float* lp,
-                int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
-                const float* tot, float* grad, hipStream_t st) {
-    PostArgs q{};
-    q.blob = (const int32_t*)graph_dev; q.utt = (const int64_t*)(ws + P.off_utt);
-    q.seq2utt = (const int32_t*)(ws + P.off_seq2utt);
-    q.gscale = gscale_dev;
-    q.lp = lp; q.strideB = strideB; q.strideT = strideT; q.E = (const float*)(ws + P.off_E);
-    q.alpha = ws + P.off_alpha; q.beta = ws + P.off_beta; q.tot = tot; q.grad = grad; q.Tmax = Tmax; q.V = V;
-    q.smax = (int)align_up(P.smax, 4);
-    size_t lds = 2 * (size_t)q.smax * 4;
-    dim3 grid(Tmax, num_seqs), block(256);
-    if (dbl) {
-        auto k = post_kernel<double>;
-        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, grid, block, lds, st, q);
-    } else {
-        auto k = post_kernel<float>;
-        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, grid, block, lds, st, q);
-    }
-    HIP_TRY(hipGetLastError());
-    return WF_OK;
-}
-
 int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                   int64_t strideB, int64_t strideT, hipStream_t st) {
     if (!P.any_compact) return WF_OK;
@@ -709,6 +730,25 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
     int64_t per = (int64_t)P.Tlong * P.kmax_compact;
     int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (per + 255) / 256), 4096);
     hipLaunchKernelGGL(gather_kernel, dim3(gx, P.B), dim3(256), 0, st, g);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
+                int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
+                float* grad, hipStream_t st) {
+    PostArgs q{};
+    q.blob = (const int32_t*)graph_dev; q.utt = (const int64_t*)(ws + P.off_utt);
+    q.seq2utt = (const int32_t*)(ws + P.off_seq2utt);
+    q.gscale = gscale_dev;
+    q.lp = lp; q.strideB = strideB; q.strideT = strideT; q.E = (const float*)(ws + P.off_E);
+    q.alpha = (const double*)(ws + P.off_alpha); q.beta = (const double*)(ws + P.off_beta);
+    q.totd = (const double*)(ws + P.off_totd); q.grad = grad; q.Tmax = Tmax; q.V = V;
+    q.smax = (int)align_up(P.smax, 4);
+    size_t lds = 2 * (size_t)q.smax * 4;
+    dim3 grid(Tmax, num_seqs), block(256);
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(post_kernel, grid, block, lds, st, q);
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
@@ -725,7 +765,7 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     hipStream_t st = (hipStream_t)stream;
     const bool dbl = flags & WF_DOUBLE_ACC;
     const bool need_ab = grad || (flags & WF_KEEP_AB);
-    const size_t ab = dbl ? 8 : 4;
+    const size_t ab = 8;
     Plan P;
     int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, need_ab ? 0 : 1, &P);
     if (rc) return rc;
@@ -737,19 +777,50 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     if (need_ab) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
     rc = upload_tables(P, ws, need_ab ? seq2utt.data() : nullptr, num_seqs, st);
     if (rc) return rc;
+    g_tm.have_fwd = g_tm.have_post = false;
+    if ((rc = tm_record(0, st))) return rc;
     rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
     if (rc) return rc;
+    if ((rc = tm_record(1, st))) return rc;
     SweepCfg c = sweep_config(P, ab);
     SweepArgs a{};
     a.blob = (const int32_t*)graph_dev; a.utt = (const int64_t*)(ws + P.off_utt);
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT;
     a.E = (const float*)(ws + P.off_E);
     a.alpha = ws + P.off_alpha; a.beta = ws + P.off_beta; a.tot = tot; a.bp = nullptr; a.fin_arc = nullptr;
-    a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.tot_double = 0;
-    if (need_ab) rc = dbl ? launch_sweep<double, M_FB>(c, a, B, st) : launch_sweep<float, M_FB>(c, a, B, st);
-    else rc = dbl ? launch_sweep<double, M_TOT_LOG>(c, a, B, st) : launch_sweep<float, M_TOT_LOG>(c, a, B, st);
+    a.totd = (double*)(ws + P.off_totd);
+    a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
+    if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);
+    else rc = dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
     if (rc) return rc;
-    if (grad) return launch_post(P, dbl, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, tot, grad, st);
+    if ((rc = tm_record(2, st))) return rc;
+    g_tm.have_fwd = g_tm.on;
+    if (grad) {
+        if ((rc = tm_record(3, st))) return rc;
+        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, st);
+        if (rc) return rc;
+        if ((rc = tm_record(4, st))) return rc;
+        g_tm.have_post = g_tm.on;
+    }
+    return WF_OK;
+}
+
+extern "C" int wf_timing_enable(int on) { g_tm.on = on != 0; g_tm.have_fwd = g_tm.have_post = false; return WF_OK; }
+
+// ms[0..2] = gather, sweep, post kernel time of the last timed call(s); -1 where not measured.
+// Synchronises on the recorded events (a measurement aid, not part of the hot path).
+extern "C" int wf_timing_read(float* ms) {
+    if (!ms) return wf_fail(WF_EINVAL, "wf_timing_read: null");
+    ms[0] = ms[1] = ms[2] = -1.f;
+    if (g_tm.have_fwd) {
+        HIP_TRY(hipEventSynchronize(g_tm.ev[2]));
+        HIP_TRY(hipEventElapsedTime(&ms[0], g_tm.ev[0], g_tm.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms[1], g_tm.ev[1], g_tm.ev[2]));
+    }
+    if (g_tm.have_post) {
+        HIP_TRY(hipEventSynchronize(g_tm.ev[4]));
+        HIP_TRY(hipEventElapsedTime(&ms[2], g_tm.ev[3], g_tm.ev[4]));
+    }
     return WF_OK;
 }
 
@@ -761,11 +832,18 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     if (!graph_dev || !log_probs || !tot || !grad || !workspace) return wf_fail(WF_EINVAL, "wf_fb_backward: null pointer");
     const bool dbl = flags & WF_DOUBLE_ACC;
     Plan P;
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, dbl ? 8 : 4, 0, &P);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
-    return launch_post(P, dbl, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, tot, grad, (hipStream_t)stream);
+    (void)dbl; (void)tot;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = tm_record(3, st))) return rc;
+    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, st);
+    if (rc) return rc;
+    if ((rc = tm_record(4, st))) return rc;
+    g_tm.have_post = g_tm.on;
+    return WF_OK;
 }
 
 extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
@@ -775,7 +853,7 @@ extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, cons
     if (!graph_dev || !log_probs || !tot || !workspace) return wf_fail(WF_EINVAL, "wf_tot_scores: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const bool dbl = flags & WF_DOUBLE_ACC;
-    const size_t ab = dbl ? 8 : 4;
+    const size_t ab = (dbl || !(flags & WF_TROPICAL)) ? 8 : 4;
     Plan P;
     int maxseq = 0;
     if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
@@ -791,10 +869,10 @@ extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, cons
     SweepArgs a{};
     a.blob = (const int32_t*)graph_dev; a.utt = (const int64_t*)(ws + P.off_utt);
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
-    a.tot = tot; a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words;
+    a.tot = tot; a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap;
     a.tot_double = dbl ? 1 : 0;
-    if (flags & WF_TROPICAL) return dbl ? launch_sweep<double, M_TOT_MAX>(c, a, B, st) : launch_sweep<float, M_TOT_MAX>(c, a, B, st);
-    return dbl ? launch_sweep<double, M_TOT_LOG>(c, a, B, st) : launch_sweep<float, M_TOT_LOG>(c, a, B, st);
+    if (flags & WF_TROPICAL) return dbl ? launch_sweep<double, double, M_TOT_MAX>(c, a, B, st) : launch_sweep<float, float, M_TOT_MAX>(c, a, B, st);
+    return dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
 }
 
 extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
@@ -824,8 +902,8 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
     a.blob = (const int32_t*)graph_dev; a.utt = (const int64_t*)(ws + P.off_utt);
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
     a.tot = best_score; a.bp = (int32_t*)(ws + P.off_bp); a.fin_arc = (int32_t*)(ws + P.off_finarc);
-    a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.tot_double = 0;
-    rc = dbl ? launch_sweep<double, M_VITERBI>(c, a, B, st) : launch_sweep<float, M_VITERBI>(c, a, B, st);
+    a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
+    rc = dbl ? launch_sweep<double, double, M_VITERBI>(c, a, B, st) : launch_sweep<float, float, M_VITERBI>(c, a, B, st);
     if (rc) return rc;
     TraceArgs t{a.blob, a.utt, a.bp, a.fin_arc, nullptr, best_arcs, B, Tmax};
     hipLaunchKernelGGL(backtrace_kernel, dim3((B + 63) / 64), dim3(64), 0, st, t);

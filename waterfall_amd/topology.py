@@ -195,13 +195,9 @@ def topology_text(name, phones):
     return "\n".join(lines) + "\n"
 
 
-def build_topology(name, phones):
-    """Returns (topo: Fsa, tokens: list[str]).  len(tokens) = Lang.num_nn_output (datapipe.py:112-114)."""
-    gen, first, nsub = TOPOLOGIES[name]
-    arcs, finals = gen(phones)
-    tokens = _tokens(phones, first, nsub)
-    tok_id = {t: i for i, t in enumerate(tokens)}
-    ph_id = {p: i for i, p in enumerate(phones)}
+def _assemble(name, phones_subset, tok_id, ph_id):
+    gen = TOPOLOGIES[name][0]
+    arcs, finals = gen(phones_subset)
     rows = [(s, d, tok_id[t], ph_id[o]) for (s, d, t, o) in arcs]
     # fstarcsort --sort_type=olabel: per state by output label (stable, then input label)
     order = sorted(range(len(rows)), key=lambda i: (rows[i][0], rows[i][3], rows[i][2]))
@@ -215,4 +211,48 @@ def build_topology(name, phones):
     for f in finals:
         out.append((f, sf, -1, 0.0))
         aux.append(-1)
-    return Fsa.from_arcs(out, sf + 1, aux), tokens
+    return Fsa.from_arcs(out, sf + 1, aux)
+
+
+class Topology:
+    """A token topology over a phone table, materialised on demand.
+
+    ``.fsa`` is the full T.fst (what ``Lang.load_topo`` loads, datapipe.py:168-181).  For large
+    tables the full CTC topology is O(P^2) arcs (25 M at P = 5000), so numerator
+    compilation uses ``restricted(phone_ids)``: the same generator run on the phones of one
+    transcript only, with token / phone ids of the full tables.  Composing a transcript with the
+    restricted topology gives exactly the graph the full topology gives (arcs that can never match
+    the transcript are the only ones left out; relative arc order is preserved).
+    """
+
+    def __init__(self, name, phones):
+        if name not in TOPOLOGIES:
+            raise KeyError(f"unknown topology {name!r}; known: {sorted(TOPOLOGIES)}")
+        self.name = name
+        self.phones = list(phones)
+        _, first, nsub = TOPOLOGIES[name]
+        self.tokens = _tokens(self.phones, first, nsub)
+        self._tok_id = {t: i for i, t in enumerate(self.tokens)}
+        self._ph_id = {p: i for i, p in enumerate(self.phones)}
+        self._fsa = None
+
+    @property
+    def num_nn_output(self):
+        return len(self.tokens)
+
+    @property
+    def fsa(self):
+        if self._fsa is None:
+            self._fsa = _assemble(self.name, self.phones, self._tok_id, self._ph_id)
+        return self._fsa
+
+    def restricted(self, phone_ids):
+        keep = set(int(i) for i in phone_ids)
+        sub = [p for i, p in enumerate(self.phones) if i in keep or p in (EPS, SIL)]
+        return _assemble(self.name, sub, self._tok_id, self._ph_id)
+
+
+def build_topology(name, phones):
+    """Returns (topo: Fsa, tokens: list[str]).  len(tokens) = Lang.num_nn_output (datapipe.py:112-114)."""
+    t = Topology(name, phones)
+    return t.fsa, t.tokens
