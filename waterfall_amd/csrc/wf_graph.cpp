@@ -159,6 +159,9 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
                 if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s;
             }
             I[WF_I_HEAVY_IN] = o_h; I[WF_I_NHEAVY_IN] = nh; I[WF_I_MAXIN] = maxin;
+            int nover = 0, over = 0;
+            for (int s = 0; s < S; ++s) if (cnt[s + 1] - cnt[s] > WF_REG_DEG) { ++nover; over = s; }
+            I[WF_I_NOVER_IN] = nover; I[WF_I_OVER_IN] = over;
         }
         // ---- outgoing CSR: emitting arcs in original order grouped by src (stable)
         {
@@ -184,6 +187,9 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
                 if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s;
             }
             I[WF_I_HEAVY_OUT] = o_h; I[WF_I_NHEAVY_OUT] = nh; I[WF_I_MAXOUT] = maxout;
+            int nover = 0, over = 0;
+            for (int s = 0; s < S; ++s) if (cnt[s + 1] - cnt[s] > WF_REG_DEG) { ++nover; over = s; }
+            I[WF_I_NOVER_OUT] = nover; I[WF_I_OVER_OUT] = over;
         }
         // ---- label(column)-sorted arcs
         {

@@ -10,6 +10,8 @@
 // A state whose in-degree (forward sweep) or out-degree (backward sweep) exceeds this is reduced
 // cooperatively by the whole workgroup instead of by one lane.
 #define WF_HEAVY_DEG 16
+// The register-resident sweep keeps up to this many arcs per state in VGPRs.
+#define WF_REG_DEG 4
 
 // header words
 enum { WF_H_MAGIC = 0, WF_H_NUM_FSAS = 1, WF_H_WORDS = 2, WF_H_MAX_LABEL = 3, WF_H_MAX_STATES = 4,
@@ -51,6 +53,10 @@ enum {
     WF_I_FINB_LOG = 31,    // [S] float: beta_T[s] = logsumexp of the final-arc weights leaving s
     WF_I_FINB_MAX = 32,    // [S] float: same in the tropical semiring
     WF_I_ARC_SRC = 33,     // [A+NF] source state of every original arc (local arc index)
+    WF_I_NOVER_IN = 34,    // number of states with in-degree > WF_REG_DEG
+    WF_I_OVER_IN = 35,     // one such state (the only one when NOVER_IN == 1)
+    WF_I_NOVER_OUT = 36,   // same for out-degree
+    WF_I_OVER_OUT = 37,
 };
 
 // per-utterance table entry written by the host for each call (int64 words)

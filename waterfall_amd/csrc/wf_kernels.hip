@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -388,6 +389,267 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// register-resident sweep: the fast path for graphs whose states have at most WF_REG_DEG arcs on
+// the swept side (every numerator topo o transcript) plus at most one high-degree
+// state (state 0 of a topology used as denominator).
+//
+// The graph does not change from frame to frame, so every lane loads the (src|column, weight)
+// descriptors of its state's arcs into VGPRs once.  A frame step is then: WF_REG_DEG independent
+// LDS reads of alpha, the adds, max, WF_REG_DEG v_exp, one v_log, one LDS write, one barrier.
+// Emissions are prefetched kPD frames ahead by the lane that will use them, straight into a
+// register ring (the frame loop is unrolled kPD times so the ring is statically indexed).
+// ------------------------------------------------------------------------------------------
+constexpr int kPD = 4;
+
+template <typename Acc, typename Sum, int MODE, int R, int HD>
+__global__ void __launch_bounds__(kMaxThreads) sweep_reg_kernel(SweepArgs p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool TROP = (MODE == M_TOT_MAX || MODE == M_VITERBI);
+    constexpr int NDIR = (MODE == M_FB) ? 2 : 1;
+    constexpr int D = WF_REG_DEG;
+    constexpr int HDN = HD > 0 ? HD : 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int u = blockIdx.x / NDIR, dir = blockIdx.x % NDIR;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int fsa = (int)U[WF_U_FSA], T = (int)U[WF_U_T];
+    const int32_t* blob = p.blob;
+    const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
+    const int S = I[WF_I_S], A = I[WF_I_A], K = I[WF_I_K], direct = I[WF_I_DIRECT];
+
+    Acc* cur = (Acc*)smem;
+    Acc* nxt = cur + p.smax;
+    Acc* red = nxt + p.smax;             // [16][2]
+    int* red_arc = (int*)(red + 32);     // [16]
+
+    const int32_t* g_off = blob + I[dir ? WF_I_OUT_OFF : WF_I_IN_OFF];
+    const int32_t* g_oth = blob + I[dir ? WF_I_OUT_DST : WF_I_IN_SRC];
+    const int32_t* g_col = blob + I[dir ? WF_I_OUT_COL : WF_I_IN_COL];
+    const float* g_w = (const float*)(blob + I[dir ? WF_I_OUT_W : WF_I_IN_W]);
+    const int32_t* arc_id = blob + I[WF_I_IN_ARC];
+    const bool has_over = HD > 0 && I[dir ? WF_I_NOVER_OUT : WF_I_NOVER_IN] > 0;
+    const int over = has_over ? I[dir ? WF_I_OVER_OUT : WF_I_OVER_IN] : -1;
+    const bool has_arcs = A > 0;
+
+    // ---- arc descriptors -> registers (padding: weight -inf, a valid state, column 0)
+    int pk[R][D];
+    float w[R][D];
+    int aid[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int sidx = tid + r * nt;
+        int a0 = 0, deg = 0;
+        if (sidx < S && sidx != over) { a0 = g_off[sidx]; deg = g_off[sidx + 1] - a0; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const bool valid = i < deg;
+            pk[r][i] = valid ? ((g_oth[a0 + i] & 0xffff) | (g_col[a0 + i] << 16)) : 0;
+            w[r][i] = valid ? g_w[a0 + i] : -INFINITY;
+            aid[r][i] = (valid && MODE == M_VITERBI) ? arc_id[a0 + i] : 0x7fffffff;
+        }
+    }
+    int hpk[HDN];
+    float hw[HDN];
+    int haid[HDN];
+    {
+        int h0 = 0, h1 = 0;
+        if (has_over) { h0 = g_off[over]; h1 = g_off[over + 1]; }
+#pragma unroll
+        for (int j = 0; j < HDN; ++j) {
+            const int a = h0 + tid + j * nt;
+            const bool valid = HD > 0 && a < h1;
+            hpk[j] = valid ? ((g_oth[a] & 0xffff) | (g_col[a] << 16)) : 0;
+            hw[j] = valid ? g_w[a] : -INFINITY;
+            haid[j] = (valid && MODE == M_VITERBI) ? arc_id[a] : 0x7fffffff;
+        }
+    }
+
+    const float* ebase;
+    int64_t epitch;
+    if (direct) {
+        ebase = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
+        epitch = p.strideT;
+    } else {
+        ebase = p.E + U[WF_U_E];
+        epitch = K;
+    }
+    auto frame_of = [&](int step) { return dir ? (T - 1 - step) : step; };
+    Acc* arena = (Acc*)(dir ? p.beta : p.alpha) + U[dir ? WF_U_BETA : WF_U_ALPHA];
+
+    {
+        const float* fb = (const float*)(blob + I[TROP ? WF_I_FINB_MAX : WF_I_FINB_LOG]);
+        for (int s = tid; s < S; s += nt) {
+            Acc v = dir ? (Acc)fb[s] : (s == 0 ? (Acc)0 : neg_inf<Acc>());
+            cur[s] = v;
+            if (MODE == M_FB) arena[(int64_t)(dir ? T : 0) * S + s] = v;
+        }
+    }
+
+    // ---- emission ring
+    float er[kPD][R * D];
+    float her[kPD][HDN];
+    // Loads are unconditional (a select around a load makes hipcc branch and drain vmcnt per element):
+    // steps past the end re-read the last frame, and a graph without arcs / an empty segment reads
+    // the blob header through a zero pitch.
+    if (!has_arcs || T == 0) { ebase = (const float*)blob; epitch = 0; }
+    const int last_step = max(T - 1, 0);
+#define WF_LOAD_FRAME(STEP, SLOT)                                                          \
+    do {                                                                                   \
+        const float* row_ = ebase + (int64_t)frame_of(min((STEP), last_step)) * epitch;    \
+        _Pragma("unroll") for (int r = 0; r < R; ++r)                                      \
+            _Pragma("unroll") for (int i = 0; i < D; ++i)                                  \
+                er[SLOT][r * D + i] = row_[(pk[r][i] >> 16) & 0xffff];                     \
+        if (HD > 0) {                                                                      \
+            _Pragma("unroll") for (int j = 0; j < HDN; ++j)                                \
+                her[SLOT][j] = row_[(hpk[j] >> 16) & 0xffff];                              \
+        }                                                                                  \
+    } while (0)
+#pragma unroll
+    for (int k = 0; k < kPD; ++k) WF_LOAD_FRAME(k, k);
+    __syncthreads();
+
+    // one frame step using (and then refilling) ring slot k; k is a constant after unrolling
+    auto do_step = [&](const int step, const int k) __attribute__((always_inline)) {
+        // consume this frame's emissions (x = w + e, the lattice arc score in fp32) before the
+        // ring slot is refilled, so that the refill can land in the same registers
+        float x[R * D], hx[HDN];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                x[r * D + i] = w[r][i] + er[k][r * D + i];
+                asm volatile("" : "+v"(x[r * D + i]));   // pin: must not sink below the refill
+            }
+#pragma unroll
+        for (int j = 0; j < HDN; ++j) {
+            hx[j] = hw[j] + her[k][j];
+            asm volatile("" : "+v"(hx[j]));
+        }
+        // keep the scheduler from hoisting the refill above the reads of the old values: that would
+        // need a second register set and a copy + vmcnt(0) on the loop back-edge
+        __builtin_amdgcn_sched_barrier(0);
+        WF_LOAD_FRAME(step + kPD, k);
+        const int f = frame_of(step);
+        Acc* store_row = (MODE == M_FB) ? arena + (int64_t)(dir ? f : f + 1) * S : nullptr;
+        int32_t* bp_row = (MODE == M_VITERBI) ? p.bp + U[WF_U_ALPHA] + (int64_t)f * S : nullptr;
+
+        // ---- the high-degree state: one arc (or HD arcs) per lane, wave + block reduction
+        if (HD > 0 && has_over) {
+            Acc hv[HDN];
+            Acc m = neg_inf<Acc>();
+            int barc = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < HDN; ++j) {
+                hv[j] = cur[hpk[j] & 0xffff] + (Acc)hx[j];
+                if (TROP) max_push(m, barc, hv[j], haid[j]);
+                else m = fmax(m, hv[j]);
+            }
+            Sum sm = 0;
+            if (!TROP) {
+#pragma unroll
+                for (int j = 0; j < HDN; ++j)
+                    sm += (m == neg_inf<Acc>()) ? (Sum)0 : fexp((Sum)(hv[j] - m));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                Acc m2 = shfl_xor(m, o);
+                if (TROP) { int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
+                else { Sum s2 = shfl_xor(sm, o); lse_merge(m, sm, m2, s2); }
+            }
+            if (nw > 1) {
+                if (lane == 0) { red[wave * 2] = m; red[wave * 2 + 1] = (Acc)sm; if (TROP) red_arc[wave] = barc; }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int x = 1; x < nw; ++x) {
+                        if (TROP) max_push(m, barc, red[x * 2], red_arc[x]);
+                        else lse_merge(m, sm, red[x * 2], (Sum)red[x * 2 + 1]);
+                    }
+                }
+            }
+            if (tid == 0) {
+                Acc val = TROP ? m : lse_value(m, sm);
+                nxt[over] = val;
+                if (MODE == M_FB) store_row[over] = val;
+                if (MODE == M_VITERBI) bp_row[over] = (m == neg_inf<Acc>()) ? -1 : barc;
+            }
+        }
+        // ---- ordinary states
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int sidx = tid + r * nt;
+            Acc v[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) v[i] = cur[pk[r][i] & 0xffff] + (Acc)x[r * D + i];
+            Acc val;
+            int barc = 0x7fffffff;
+            if (TROP) {
+                val = neg_inf<Acc>();
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                    if (v[i] > val) { val = v[i]; barc = aid[r][i]; }
+            } else {
+                Acc m = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
+                Sum sm = 0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) sm += fexp((Sum)(v[i] - m));
+                val = (m == neg_inf<Acc>()) ? m : m + (Acc)flog(sm);
+            }
+            if (sidx < S && sidx != over) {
+                nxt[sidx] = val;
+                if (MODE == M_FB) store_row[sidx] = val;
+                if (MODE == M_VITERBI) bp_row[sidx] = (val == neg_inf<Acc>()) ? -1 : barc;
+            }
+        }
+        __syncthreads();
+        Acc* t_ = cur; cur = nxt; nxt = t_;
+    };
+    int t0 = 0;
+    for (; t0 + kPD <= T; t0 += kPD) {   // full groups: no per-step guard, the ring stays in place
+#pragma unroll
+        for (int k = 0; k < kPD; ++k) do_step(t0 + k, k);
+    }
+#pragma unroll
+    for (int k = 0; k < kPD; ++k)
+        if (t0 + k < T) do_step(t0 + k, k);
+#undef WF_LOAD_FRAME
+
+    // ---- forward: total score over final arcs (block reduction)
+    if (dir == 0) {
+        const int NF = I[WF_I_NF];
+        const int32_t* fsrc = blob + I[WF_I_FIN_SRC];
+        const float* fw = (const float*)(blob + I[WF_I_FIN_W]);
+        const int32_t* farc = blob + I[WF_I_FIN_ARC];
+        Acc m = neg_inf<Acc>();
+        Sum sm = 0;
+        int barc = 0x7fffffff;
+        for (int i = tid; i < NF; i += nt) {
+            Acc v = cur[fsrc[i]] + (Acc)fw[i];
+            if (TROP) max_push(m, barc, v, farc[i]);
+            else lse_push(m, sm, v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            Acc m2 = shfl_xor(m, o);
+            if (TROP) { int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
+            else { Sum s2 = shfl_xor(sm, o); lse_merge(m, sm, m2, s2); }
+        }
+        if (lane == 0) { red[wave * 2] = m; red[wave * 2 + 1] = (Acc)sm; if (TROP) red_arc[wave] = barc; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int x = 1; x < nw; ++x) {
+                if (TROP) max_push(m, barc, red[x * 2], red_arc[x]);
+                else lse_merge(m, sm, red[x * 2], (Sum)red[x * 2 + 1]);
+            }
+            Acc val = TROP ? m : lse_value(m, sm);
+            if (p.tot_double) ((double*)p.tot)[u] = (double)val;
+            else ((float*)p.tot)[u] = (float)val;
+            if (MODE == M_FB && p.totd) p.totd[u] = (double)val;
+            if (MODE == M_VITERBI) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // emission gather (compact graphs)
 // ------------------------------------------------------------------------------------------
 struct GatherArgs {
@@ -543,6 +805,9 @@ struct Plan {
     std::vector<int64_t> utt;  // B * WF_U_WORDS
     int smax = 0, kmax_compact = 0, kmax = 0, amax = 0, hmax = 0;
     bool any_compact = false, any_heavy = false, arcs_lds_ok = true;
+    // register-resident sweep eligibility (per direction)
+    bool reg_ok_in = true, reg_ok_out = true;
+    int over_deg_in = 0, over_deg_out = 0;
     int64_t n_E = 0, n_ab = 0;
     int Tlong = 0;
 };
@@ -585,6 +850,10 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         if (I[WF_I_NHEAVY_IN] || I[WF_I_NHEAVY_OUT]) P->any_heavy = true;
         P->hmax = std::max(P->hmax, std::max((int)I[WF_I_NHEAVY_IN], (int)I[WF_I_NHEAVY_OUT]));
         if (I[WF_I_S] > 65535 || I[WF_I_K] > 65535) P->arcs_lds_ok = false;
+        if (I[WF_I_NOVER_IN] > 1) P->reg_ok_in = false;
+        if (I[WF_I_NOVER_OUT] > 1) P->reg_ok_out = false;
+        if (I[WF_I_NOVER_IN] == 1) P->over_deg_in = std::max(P->over_deg_in, (int)I[WF_I_MAXIN]);
+        if (I[WF_I_NOVER_OUT] == 1) P->over_deg_out = std::max(P->over_deg_out, (int)I[WF_I_MAXOUT]);
         row0 += T;
     }
     P->n_E = nE; P->n_ab = nab;
@@ -673,6 +942,49 @@ int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
     else if (c.estage) WF_LAUNCH(false, true);
     else WF_LAUNCH(false, false);
 #undef WF_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+// ---- register-resident sweep: eligibility and launch
+struct RegCfg {
+    bool ok = false;
+    int threads = 0, R = 1, HD = 0, smax = 0;
+    size_t lds = 0;
+};
+
+RegCfg reg_config(const Plan& P, size_t acc_bytes, bool both_dirs) {
+    RegCfg c;
+    if (getenv("WF_NO_REG_SWEEP")) return c;
+    if (!P.arcs_lds_ok || P.smax > 2 * kMaxThreads || !P.reg_ok_in || (both_dirs && !P.reg_ok_out)) return c;
+    c.R = P.smax <= kMaxThreads ? 1 : 2;
+    c.threads = std::max(64, (int)align_up((P.smax + c.R - 1) / c.R, 64));
+    const int od = std::max(P.over_deg_in, both_dirs ? P.over_deg_out : 0);
+    c.HD = (od + c.threads - 1) / c.threads;
+    if (c.HD > 2) return c;
+    c.smax = (int)align_up(P.smax, 4);
+    c.lds = 2 * (size_t)c.smax * acc_bytes + 32 * acc_bytes + 64;
+    c.ok = true;
+    return c;
+}
+
+template <typename Acc, typename Sum, int MODE>
+int launch_sweep_reg(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
+    const int ndir = (MODE == M_FB) ? 2 : 1;
+    dim3 grid(B * ndir), block(c.threads);
+    a.smax = c.smax;
+#define WF_LAUNCH_REG(RR, HH)                                                                   \
+    hipLaunchKernelGGL((sweep_reg_kernel<Acc, Sum, MODE, RR, HH>), grid, block, c.lds, st, a)
+    if (c.R == 1) {
+        if (c.HD == 0) WF_LAUNCH_REG(1, 0);
+        else if (c.HD == 1) WF_LAUNCH_REG(1, 1);
+        else WF_LAUNCH_REG(1, 2);
+    } else {
+        if (c.HD == 0) WF_LAUNCH_REG(2, 0);
+        else if (c.HD == 1) WF_LAUNCH_REG(2, 1);
+        else WF_LAUNCH_REG(2, 2);
+    }
+#undef WF_LAUNCH_REG
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
@@ -790,7 +1102,9 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     a.alpha = ws + P.off_alpha; a.beta = ws + P.off_beta; a.tot = tot; a.bp = nullptr; a.fin_arc = nullptr;
     a.totd = (double*)(ws + P.off_totd);
     a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
-    if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);
+    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, ab, need_ab);
+    if (rc_.ok) rc = need_ab ? launch_sweep_reg<double, float, M_FB>(rc_, a, B, st) : launch_sweep_reg<double, float, M_TOT_LOG>(rc_, a, B, st);
+    else if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);
     else rc = dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
     if (rc) return rc;
     if ((rc = tm_record(2, st))) return rc;
@@ -871,6 +1185,9 @@ extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, cons
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
     a.tot = tot; a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap;
     a.tot_double = dbl ? 1 : 0;
+    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, ab, false);
+    if (rc_.ok) return (flags & WF_TROPICAL) ? launch_sweep_reg<float, float, M_TOT_MAX>(rc_, a, B, st)
+                                             : launch_sweep_reg<double, float, M_TOT_LOG>(rc_, a, B, st);
     if (flags & WF_TROPICAL) return dbl ? launch_sweep<double, double, M_TOT_MAX>(c, a, B, st) : launch_sweep<float, float, M_TOT_MAX>(c, a, B, st);
     return dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
 }
@@ -903,7 +1220,9 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
     a.tot = best_score; a.bp = (int32_t*)(ws + P.off_bp); a.fin_arc = (int32_t*)(ws + P.off_finarc);
     a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
-    rc = dbl ? launch_sweep<double, double, M_VITERBI>(c, a, B, st) : launch_sweep<float, float, M_VITERBI>(c, a, B, st);
+    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, ab, false);
+    if (rc_.ok) rc = launch_sweep_reg<float, float, M_VITERBI>(rc_, a, B, st);
+    else rc = dbl ? launch_sweep<double, double, M_VITERBI>(c, a, B, st) : launch_sweep<float, float, M_VITERBI>(c, a, B, st);
     if (rc) return rc;
     TraceArgs t{a.blob, a.utt, a.bp, a.fin_arc, nullptr, best_arcs, B, Tmax};
     hipLaunchKernelGGL(backtrace_kernel, dim3((B + 63) / 64), dim3(64), 0, st, t);
