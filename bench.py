@@ -118,10 +118,12 @@ class Workload:
         V = self.V
         gather = 8 * self.compact_K_frames                      # read 4 B + write 4 B per gathered element
         sweep = 2 * 4 * self.K_frames + 2 * 8 * self.S_frames   # emissions read by both sweeps + alpha/beta rows out
-        post = 4 * V * self.B * self.T + 2 * 8 * self.S_frames + 4 * self.K_frames  # grad rows + alpha/beta in + emissions
+        zero = 4 * V * self.B * self.T                          # zero-fill of the gradient box (side stream)
+        direct_K_frames = self.K_frames - self.compact_K_frames
+        post = 2 * 8 * self.S_frames + 4 * self.K_frames + 4 * self.compact_K_frames + 4 * direct_K_frames  # alpha/beta in + emissions in + values out
         # SURVEY.md 8(d) whole-path figure: 4V (lp row) + 4V (grad row) + 8S (alpha spill + reload) per frame
         path = (8 * V) * self.frames + 8 * self.S_frames
-        return {"gather": gather, "sweep": sweep, "post": post, "path_survey_8d": path}
+        return {"gather": gather, "sweep": sweep, "post": post, "zero": zero, "path_survey_8d": path}
 
 
 def time_steps(wl, steps, warmup, dist, stream, fused_buf):
@@ -153,14 +155,14 @@ def kernel_times(wl, stream, reps=20):
     the launch stream around each kernel."""
     lib = _lib.lib()
     lib.wf_timing_enable(1)
-    acc = np.zeros(3)
-    ms = (C.c_float * 3)()
+    acc = np.zeros(4)
+    ms = (C.c_float * 4)()
     for _ in range(reps):
         wl.step(stream)
         _lib.check(lib.wf_timing_read(ms))
         acc += np.array(list(ms))
     lib.wf_timing_enable(0)
-    return dict(zip(("gather", "sweep", "post"), (acc / reps).tolist()))
+    return dict(zip(("gather", "sweep", "post", "zero"), (acc / reps).tolist()))
 
 
 def cpu_baseline(wl, budget_s=12.0):

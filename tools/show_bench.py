@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Pretty-print the JSON line of a bench.py log."""
+import json
+import sys
+for line in open(sys.argv[1]):
+    if not line.startswith("{"):
+        continue
+    d = json.loads(line)
+    print(f"value {d['value']:.4g} {d['unit']}  ms/step {d['ms_per_step']:.4f}  n_gpus {d['n_gpus']}")
+    for k, v in d.get("kernels", {}).items():
+        print(f"   {k:7s} {v['avg_ms']*1e3:9.1f} us  {v['GBps'] or 0:8.1f} GB/s")
+    if "roofline" in d:
+        r = d["roofline"]
+        print(f"   roofline: {r['kernel']} {r['achieved']:.1f}/{r['peak']} GB/s frac {r['frac']:.4f}")
+    if "cpu_baseline" in d:
+        c = d["cpu_baseline"]
+        print(f"   cpu: {c['value']:.4g} frames/s on {c['cores']} cores ({c['kind']})")
+    for k, v in d.get("other_workloads", {}).items():
+        print(f"   {k:28s} {v['frames_per_s']:.4g} f/s  {v['ms_per_step']:.4f} ms  " +
+              " ".join(f"{a}={b*1e3:.1f}us" for a, b in v["kernels_ms"].items()))

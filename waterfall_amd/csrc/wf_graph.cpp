@@ -78,7 +78,7 @@ int plan_fsa(const wf_graph_host* gh, int g, FsaPlan* p, std::vector<int>* label
     size_t w = 0;
     w += pad4(S + 1) + 4 * pad4(p->A);          // in_off, in_src, in_col, in_w, in_arc
     w += pad4(S + 1) + 3 * pad4(p->A);          // out_off, out_dst, out_col, out_w
-    w += pad4(p->K + 1) + 3 * pad4(p->A);       // lab_off, lab_src, lab_dst, lab_w
+    w += pad4(p->K + 1) + 4 * pad4(p->A);       // lab_off, lab_src, lab_dst, lab_w, lab_col
     w += pad4(p->K);                            // labels
     w += 3 * pad4(p->NF);                       // fin_src, fin_w, fin_arc
     w += 2 * pad4(S);                           // heavy_in, heavy_out (upper bound)
@@ -194,7 +194,8 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
         // ---- label(column)-sorted arcs
         {
             const int K = p.K;
-            int o_off = take(K + 1), o_src = take(A), o_dst = take(A), o_w = take(A), o_lab = take(K);
+            int o_off = take(K + 1), o_src = take(A), o_dst = take(A), o_w = take(A), o_lab = take(K), o_lcol = take(A);
+            I[WF_I_LAB_COL] = o_lcol;
             I[WF_I_LAB_OFF] = o_off; I[WF_I_LAB_SRC] = o_src; I[WF_I_LAB_DST] = o_dst; I[WF_I_LAB_W] = o_w; I[WF_I_LABELS] = o_lab;
             std::vector<int> cnt(K + 1, 0);
             for (int a : p.em) cnt[col_of(arcs[4 * a + 2]) + 1]++;
@@ -207,6 +208,7 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
                 B[o_src + q] = arcs[4 * a + 0];
                 B[o_dst + q] = arcs[4 * a + 1];
                 B[o_w + q] = arcs[4 * a + 3];
+                B[o_lcol + q] = col_of(arcs[4 * a + 2]);
             }
             for (int k = 0; k < K; ++k) B[o_lab + k] = p.direct ? k : labs[k];
             I[WF_I_MAXLAB_DEG] = maxdeg;

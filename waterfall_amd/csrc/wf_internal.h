@@ -57,6 +57,7 @@ enum {
     WF_I_OVER_IN = 35,     // one such state (the only one when NOVER_IN == 1)
     WF_I_NOVER_OUT = 36,   // same for out-degree
     WF_I_OVER_OUT = 37,
+    WF_I_LAB_COL = 38,     // [A] column of every column-sorted arc
 };
 
 // per-utterance table entry written by the host for each call (int64 words)
@@ -69,5 +70,9 @@ enum {
     WF_U_BETA = 5,
     WF_U_E = 6,      // element offset of the gathered emission rows (compact mode)
     WF_U_ROW0 = 7,   // first row index of this utterance in the flattened (b,t) row list
-    WF_U_WORDS = 8,
+    // copies of the FSA's info words that post kernels need (saves one dependent load)
+    WF_U_S = 8, WF_U_A = 9, WF_U_K = 10, WF_U_DIRECT = 11, WF_U_MAXLABDEG = 12,
+    WF_U_LAB_OFF = 13, WF_U_LAB_SRC = 14, WF_U_LAB_DST = 15, WF_U_LAB_COL = 16, WF_U_LAB_W = 17,
+    WF_U_LABELS = 18,
+    WF_U_WORDS = 24,
 };

@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
 // Emissions are prefetched kPD frames ahead by the lane that will use them, straight into a
 // register ring (the frame loop is unrolled kPD times so the ring is statically indexed).
 // ------------------------------------------------------------------------------------------
-constexpr int kPD = 4;
+constexpr int kPD = 8;
 
 template <typename Acc, typename Sum, int MODE, int R, int HD>
 __global__ void __launch_bounds__(kMaxThreads) sweep_reg_kernel(SweepArgs p) {
@@ -694,68 +694,255 @@ struct PostArgs {
     const double* totd;
     float* grad;
     int Tmax, V, smax;
+    int ecap;       // LDS floats reserved for the staged emission row (compact graphs), 0 = none
+    int acap;       // LDS floats reserved for per-arc posteriors (arc-parallel mode), 0 = column loop
+    int skip_zero;  // rows were zero-filled by zero_kernel already: only scatter the K values
+    int fr;         // frames per workgroup
+    int ablate;     // debugging aid (WF_POST_ABLATE): skips parts of post_small_kernel to find its bottleneck
 };
 
+// zero n floats starting at p (4-byte aligned) with 16-byte stores where alignment allows
+__device__ __forceinline__ void zero_span(float* p, int n, int tid, int nt) {
+    int head = (int)(((16u - (unsigned)((uintptr_t)p & 15u)) & 15u) >> 2);
+    head = min(head, n);
+    if (tid < head) p[tid] = 0.f;
+    float4* q = (float4*)(p + head);
+    const int n4 = (n - head) >> 2;
+    for (int i = tid; i < n4; i += nt) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int t0 = head + n4 * 4;
+    if (tid < n - t0) p[t0 + tid] = 0.f;
+}
+
+// Zero-fill of the gradient box, launched on a side stream so that it overlaps the latency-bound
+// sweeps (which leave most of the chip idle).  grid = (Tmax, N).
+struct ZeroArgs {
+    float* grad;
+    int64_t strideB, strideT;
+    int V;
+};
+// contiguous box: grid-stride 16-byte non-temporal stores (streaming: do not displace the gathered
+// emissions and the graph from L2 while the sweeps are running)
+__global__ void __launch_bounds__(256) zero_flat_kernel(float4* p, size_t n4, float* tail, int ntail) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f z = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        __builtin_nontemporal_store(z, (v4f*)p + i);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+
+__global__ void __launch_bounds__(256) zero_kernel(ZeroArgs p) {
+    zero_span(p.grad + (int64_t)blockIdx.y * p.strideB + (int64_t)blockIdx.x * p.strideT, p.V, threadIdx.x, blockDim.x);
+}
+
+// p.fr consecutive frames are handled by one workgroup.  Measured on cfg3: fr = 1 with 64-lane
+// workgroups (16 000 independent waves, 2 residency rounds) beats fr = 8 (each frame costs a chain of
+// dependent L2 loads that only parallelism across workgroups hides).
+
+// SMALL: S <= blockDim and the staged emission row fits one element per lane, so the next frame's
+// alpha / beta / emission values are prefetched into registers while the current frame is reduced.
+template <bool SMALL>
 __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double wmax[4];
     float* la = (float*)smem;   // alpha_t[s] - a_ref
     float* lb = la + p.smax;    // beta_{t+1}[s] - (tot - a_ref)
+    float* le = lb + p.smax;    // emission row (compact graphs)
+    float* lpost = le + p.ecap; // per-arc posteriors (arc-parallel mode)
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int f = blockIdx.x, q = blockIdx.y;
-    float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
+    const int f0 = blockIdx.x * p.fr, q = blockIdx.y;
+    const int f1 = min(f0 + p.fr, p.Tmax);
+    float* gbase = p.grad + (int64_t)q * p.strideB;
     const int V = p.V;
     const int u = p.seq2utt[q];
-    bool live = u >= 0;
-    const int64_t* U = p.utt + (int64_t)(live ? u : 0) * WF_U_WORDS;
+    const bool has = u >= 0;
+    const int64_t* U = p.utt + (int64_t)(has ? u : 0) * WF_U_WORDS;
     const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
-    const int t = f - start;
-    const double tot = live ? p.totd[u] : 0.0;
-    live = live && t >= 0 && t < T && tot != (double)-INFINITY;
-    if (!live) {
-        for (int v = tid; v < V; v += nt) grow[v] = 0.f;
+    const double tot = has ? p.totd[u] : 0.0;
+    if (!has || tot == (double)-INFINITY || f0 >= start + T || f1 <= start) {
+        if (!p.skip_zero)
+            for (int f = f0; f < f1; ++f) zero_span(gbase + (int64_t)f * p.strideT, V, tid, nt);
         return;
     }
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
-    const int S = I[WF_I_S], K = I[WF_I_K], direct = I[WF_I_DIRECT];
-    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
-    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
-    // reference point: the best alpha of this frame, so that both LDS vectors hold small numbers
-    double mx = (double)-INFINITY;
-    for (int s = tid; s < S; s += nt) mx = fmax(mx, arow[s]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, shfl_xor(mx, o));
-    if ((tid & 63) == 0) wmax[tid >> 6] = mx;
-    __syncthreads();
-    const double a_ref = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
-    const double b_ref = tot - a_ref;
-    for (int s = tid; s < S; s += nt) {
-        la[s] = (float)(arow[s] - a_ref);
-        lb[s] = (float)(brow[s] - b_ref);
-    }
+    const int S = I[WF_I_S], A = I[WF_I_A], K = I[WF_I_K], direct = I[WF_I_DIRECT];
+    const double* abase = p.alpha + U[WF_U_ALPHA];
+    const double* bbase = p.beta + U[WF_U_BETA];
+    const float* ebase = direct ? p.lp + (int64_t)q * p.strideB + (int64_t)start * p.strideT : p.E + U[WF_U_E];
+    const int64_t epitch = direct ? p.strideT : K;
+    const bool stage_e = !direct && K <= p.ecap;
     const int32_t* loff = p.blob + I[WF_I_LAB_OFF];
     const int32_t* lsrc = p.blob + I[WF_I_LAB_SRC];
     const int32_t* ldst = p.blob + I[WF_I_LAB_DST];
+    const int32_t* lcol = p.blob + I[WF_I_LAB_COL];
     const float* lw = (const float*)(p.blob + I[WF_I_LAB_W]);
     const int32_t* labels = p.blob + I[WF_I_LABELS];
     const float gs = p.gscale ? p.gscale[u] : 1.f;
-    const float* erow = direct ? p.lp + (int64_t)q * p.strideB + (int64_t)f * p.strideT
-                               : p.E + U[WF_U_E] + (int64_t)t * K;
-    if (!direct) {
-        for (int v = tid; v < V; v += nt) grow[v] = 0.f;
-    } else {
-        for (int v = K + tid; v < V; v += nt) grow[v] = 0.f;
+    const bool arcpar = A <= p.acap && I[WF_I_MAXLAB_DEG] > 8;
+    const int nwv = nt >> 6;
+
+    // SMALL: register prefetch of frame t's values (one alpha, one beta, one emission per lane)
+    double pa = (double)-INFINITY, pb = (double)-INFINITY;
+    float pe = 0.f;
+    auto prefetch = [&](int t) {
+        if (!SMALL || t < 0 || t >= T) return;
+        if (tid < S) { pa = abase[(int64_t)t * S + tid]; pb = bbase[(int64_t)(t + 1) * S + tid]; }
+        if (stage_e && tid < K) pe = ebase[(int64_t)t * epitch + tid];
+    };
+    prefetch(max(f0 - start, 0));
+
+    for (int f = f0; f < f1; ++f) {
+        float* grow = gbase + (int64_t)f * p.strideT;
+        const int t = f - start;
+        if (t < 0 || t >= T) {   // uniform
+            if (!p.skip_zero) zero_span(grow, V, tid, nt);
+            continue;
+        }
+        const double* arow = abase + (int64_t)t * S;
+        const double* brow = bbase + (int64_t)(t + 1) * S;
+        const float* erow = ebase + (int64_t)t * epitch;
+        // reference point: the best alpha of this frame, so that both LDS vectors hold small numbers
+        double mx = (double)-INFINITY;
+        double ca = pa, cb = pb;
+        if (SMALL) {
+            mx = ca;
+            if (stage_e && tid < K) le[tid] = pe;
+            prefetch(t + 1 < T && f + 1 < f1 ? t + 1 : -1);
+        } else {
+            for (int s = tid; s < S; s += nt) mx = fmax(mx, arow[s]);
+            if (stage_e)
+                for (int k = tid; k < K; k += nt) le[k] = erow[k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, shfl_xor(mx, o));
+        if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+        if (!p.skip_zero) {
+            if (!direct) zero_span(grow, V, tid, nt);
+            else if (K < V) zero_span(grow + K, V - K, tid, nt);
+        }
+        __syncthreads();
+        double a_ref = wmax[0];
+        for (int x = 1; x < nwv; ++x) a_ref = fmax(a_ref, wmax[x]);
+        const double b_ref = tot - a_ref;
+        if (SMALL) {
+            if (tid < S) { la[tid] = (float)(ca - a_ref); lb[tid] = (float)(cb - b_ref); }
+        } else {
+            for (int s = tid; s < S; s += nt) {
+                la[s] = (float)(arow[s] - a_ref);
+                lb[s] = (float)(brow[s] - b_ref);
+            }
+        }
+        __syncthreads();
+        if (arcpar) {
+            // arc-parallel: a column shared by many arcs (the blank of a CTC numerator sits on ~40% of
+            // the arcs) would serialise one lane; compute one posterior per lane, then add per column in
+            // arc order (fixed order => bit-stable, no atomics)
+            for (int a = tid; a < A; a += nt) {
+                const int c = lcol[a];
+                const float e = stage_e ? le[c] : erow[c];
+                lpost[a] = fexp(la[lsrc[a]] + (lw[a] + e) + lb[ldst[a]]);
+            }
+            __syncthreads();
+            for (int k = tid; k < K; k += nt) {
+                const int a0 = loff[k], a1 = loff[k + 1];
+                float acc = 0.f;
+                for (int a = a0; a < a1; ++a) acc += lpost[a];
+                grow[direct ? k : labels[k]] = gs * acc;
+            }
+        } else {
+            for (int k = tid; k < K; k += nt) {
+                const int a0 = loff[k], a1 = loff[k + 1];
+                const float e = stage_e ? le[k] : erow[k];
+                float acc = 0.f;
+                for (int a = a0; a < a1; ++a) {
+                    float x = la[lsrc[a]] + (lw[a] + e) + lb[ldst[a]];
+                    acc += fexp(x);   // exp(-inf) = 0 for dead states
+                }
+                grow[direct ? k : labels[k]] = gs * acc;
+            }
+        }
+        __syncthreads();   // la / lb / le / lpost are reused by the next frame
+    }
+}
+
+// One wavefront per gradient row for small compact graphs (numerators): S, A, K <= 64 * kPS.
+// Everything the row needs is fetched in two batches of independent loads (header, then alpha /
+// beta / emissions / arc descriptors together), so a wave pays ~3 memory latencies in all and the
+// 16 000 rows of a batch run as 16 000 independent waves.  Rows are pre-zeroed (skip_zero).
+constexpr int kPS = 8;
+
+__global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* la = (float*)smem;
+    float* lb = la + p.smax;
+    float* le = lb + p.smax;
+    float* lpost = le + p.ecap;
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x, q = blockIdx.y;
+    const int u = p.seq2utt[q];
+    if (u < 0) return;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
+    const int t = f - start;
+    const double tot = p.totd[u];
+    if (t < 0 || t >= T || tot == (double)-INFINITY) return;
+    const int S = (int)U[WF_U_S], A = (int)U[WF_U_A], K = (int)U[WF_U_K];
+    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    const float* erow = p.E + U[WF_U_E] + (int64_t)t * K;
+    const int32_t* loff = p.blob + U[WF_U_LAB_OFF];
+    const int32_t* lsrc = p.blob + U[WF_U_LAB_SRC];
+    const int32_t* ldst = p.blob + U[WF_U_LAB_DST];
+    const int32_t* lcol = p.blob + U[WF_U_LAB_COL];
+    const float* lw = (const float*)(p.blob + U[WF_U_LAB_W]);
+    const int32_t* labels = p.blob + U[WF_U_LABELS];
+    const float gs = p.gscale ? p.gscale[u] : 1.f;
+    float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
+
+    // ---- batch 2: all independent loads (indices clamped so that no load is conditional)
+    double av[kPS], bv[kPS];
+    float ev[kPS];
+    int asrc[kPS], adst[kPS], acol[kPS];
+    float aw[kPS];
+    int k0[2], k1[2], klab[2];
+#pragma unroll
+    for (int i = 0; i < kPS; ++i) {
+        const int s = min(lane + i * 64, S - 1);
+        av[i] = arow[s];
+        bv[i] = brow[s];
+        ev[i] = erow[min(lane + i * 64, K - 1)];
+        const int a = min(lane + i * 64, A - 1);
+        asrc[i] = lsrc[a]; adst[i] = ldst[a]; acol[i] = lcol[a]; aw[i] = lw[a];
+    }
+    double mx = (double)-INFINITY;
+#pragma unroll
+    for (int i = 0; i < kPS; ++i) mx = fmax(mx, av[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, shfl_xor(mx, o));
+    const double a_ref = mx, b_ref = tot - mx;
+#pragma unroll
+    for (int i = 0; i < kPS; ++i) {
+        const int s = lane + i * 64;
+        if (s < S) { la[s] = (float)(av[i] - a_ref); lb[s] = (float)(bv[i] - b_ref); }
+        if (s < K) le[s] = ev[i];
     }
     __syncthreads();
-    for (int k = tid; k < K; k += nt) {
+#pragma unroll
+    for (int i = 0; i < kPS; ++i) {
+        const int a = lane + i * 64;
+        if (a < A) lpost[a] = fexp(la[asrc[i]] + (aw[i] + le[acol[i]]) + lb[adst[i]]);
+    }
+    __syncthreads();
+    // per-column sums in arc order (bit-stable)
+    for (int k = lane; k < K; k += 64) {
         const int a0 = loff[k], a1 = loff[k + 1];
-        const float e = erow[k];
+        const int lab = labels[k];
         float acc = 0.f;
-        for (int a = a0; a < a1; ++a) {
-            float x = la[lsrc[a]] + (lw[a] + e) + lb[ldst[a]];
-            acc += fexp(x);   // exp(-inf) = 0 for dead states
-        }
-        grow[direct ? k : labels[k]] = gs * acc;
+        if (p.ablate & 2) acc = lpost[a0];
+        else
+            for (int a = a0; a < a1; ++a) acc += lpost[a];
+        if (!(p.ablate & 1)) grow[lab] = gs * acc;
+        else if (acc == 123.456f) grow[lab] = acc;
     }
 }
 
@@ -803,8 +990,8 @@ struct Plan {
     size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_totd = 0, off_E = 0, off_alpha = 0, off_beta = 0,
            off_bp = 0, off_finarc = 0, total = 0;
     std::vector<int64_t> utt;  // B * WF_U_WORDS
-    int smax = 0, kmax_compact = 0, kmax = 0, amax = 0, hmax = 0;
-    bool any_compact = false, any_heavy = false, arcs_lds_ok = true;
+    int smax = 0, kmax_compact = 0, kmax = 0, amax = 0, hmax = 0, maxlabdeg = 0;
+    bool any_compact = false, all_compact = true, any_heavy = false, arcs_lds_ok = true;
     // register-resident sweep eligibility (per direction)
     bool reg_ok_in = true, reg_ok_out = true;
     int over_deg_in = 0, over_deg_out = 0;
@@ -841,11 +1028,17 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         int64_t* U = &P->utt[(size_t)i * WF_U_WORDS];
         U[WF_U_FSA] = g; U[WF_U_SEQ] = b; U[WF_U_START] = st; U[WF_U_T] = T;
         U[WF_U_ALPHA] = nab; U[WF_U_BETA] = nab; U[WF_U_E] = nE; U[WF_U_ROW0] = row0;
+        U[WF_U_S] = I[WF_I_S]; U[WF_U_A] = I[WF_I_A]; U[WF_U_K] = I[WF_I_K]; U[WF_U_DIRECT] = I[WF_I_DIRECT];
+        U[WF_U_MAXLABDEG] = I[WF_I_MAXLAB_DEG];
+        U[WF_U_LAB_OFF] = I[WF_I_LAB_OFF]; U[WF_U_LAB_SRC] = I[WF_I_LAB_SRC]; U[WF_U_LAB_DST] = I[WF_I_LAB_DST];
+        U[WF_U_LAB_COL] = I[WF_I_LAB_COL]; U[WF_U_LAB_W] = I[WF_I_LAB_W]; U[WF_U_LABELS] = I[WF_I_LABELS];
         nab += (int64_t)(T + 1) * I[WF_I_S];
+        if (I[WF_I_DIRECT]) P->all_compact = false;
         if (!I[WF_I_DIRECT]) { nE += (int64_t)T * I[WF_I_K]; P->any_compact = true; P->kmax_compact = std::max(P->kmax_compact, (int)I[WF_I_K]); }
         P->kmax = std::max(P->kmax, (int)I[WF_I_K]);
         P->smax = std::max(P->smax, (int)I[WF_I_S]);
         P->amax = std::max(P->amax, (int)I[WF_I_A]);
+        P->maxlabdeg = std::max(P->maxlabdeg, (int)I[WF_I_MAXLAB_DEG]);
         P->Tlong = std::max(P->Tlong, T);
         if (I[WF_I_NHEAVY_IN] || I[WF_I_NHEAVY_OUT]) P->any_heavy = true;
         P->hmax = std::max(P->hmax, std::max((int)I[WF_I_NHEAVY_IN], (int)I[WF_I_NHEAVY_OUT]));
@@ -878,9 +1071,9 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
 // around each kernel of the last wf_fb_logsum / wf_fb_backward call of this thread.
 struct Timing {
     bool on = false;
-    hipEvent_t ev[5] = {};   // t0 | gather | sweep | (post t0) | post
+    hipEvent_t ev[7] = {};   // t0 | gather | sweep | (post t0) | post | zero t0 | zero t1
     bool made = false;
-    bool have_fwd = false, have_post = false;
+    bool have_fwd = false, have_post = false, have_zero = false;
 };
 thread_local Timing g_tm;
 int tm_record(int i, hipStream_t st) {
@@ -890,6 +1083,26 @@ int tm_record(int i, hipStream_t st) {
         g_tm.made = true;
     }
     HIP_TRY(hipEventRecord(g_tm.ev[i], st));
+    return WF_OK;
+}
+
+// side stream for work that can overlap the latency-bound sweeps (one per device, per host thread)
+struct Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+thread_local Side g_side[16];
+int side_get(Side** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return wf_fail(WF_EUNSUPPORTED, "device index %d", dev);
+    Side& s = g_side[dev];
+    if (!s.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    }
+    *out = &s;
     return WF_OK;
 }
 
@@ -1048,7 +1261,7 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
 
 int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                 int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
-                float* grad, hipStream_t st) {
+                float* grad, bool skip_zero, hipStream_t st) {
     PostArgs q{};
     q.blob = (const int32_t*)graph_dev; q.utt = (const int64_t*)(ws + P.off_utt);
     q.seq2utt = (const int32_t*)(ws + P.off_seq2utt);
@@ -1057,10 +1270,30 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     q.alpha = (const double*)(ws + P.off_alpha); q.beta = (const double*)(ws + P.off_beta);
     q.totd = (const double*)(ws + P.off_totd); q.grad = grad; q.Tmax = Tmax; q.V = V;
     q.smax = (int)align_up(P.smax, 4);
-    size_t lds = 2 * (size_t)q.smax * 4;
-    dim3 grid(Tmax, num_seqs), block(256);
-    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(post_kernel, grid, block, lds, st, q);
+    q.ecap = (P.any_compact && P.kmax_compact <= 8192) ? (int)align_up(P.kmax_compact, 4) : 0;
+    q.acap = (P.maxlabdeg > 8 && P.amax <= 8192) ? (int)align_up(P.amax, 4) : 0;
+    q.skip_zero = skip_zero ? 1 : 0;
+    size_t lds = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
+    if (skip_zero && !getenv("WF_NO_POST_SMALL") && P.all_compact && P.amax >= 1 && P.amax <= 64 * kPS && P.smax <= 64 * kPS &&
+        P.kmax_compact <= 64 * kPS && q.ecap > 0) {
+        q.acap = (int)align_up(P.amax, 4);
+        q.ablate = getenv("WF_POST_ABLATE") ? atoi(getenv("WF_POST_ABLATE")) : 0;
+        size_t lds2 = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
+        hipLaunchKernelGGL(post_small_kernel, dim3(Tmax, num_seqs), dim3(64), lds2, st, q);
+        HIP_TRY(hipGetLastError());
+        return WF_OK;
+    }
+    const bool tiny_rows = skip_zero || V <= 1024;   // a 64-lane workgroup would be slow at zero-filling long rows
+    const int threads = (P.amax <= 1024 && P.smax <= 512 && tiny_rows) ? 64 : 256;
+    q.fr = 1;
+    dim3 grid((Tmax + q.fr - 1) / q.fr, num_seqs), block(threads);
+    const bool small = P.smax <= threads && (q.ecap == 0 || P.kmax_compact <= threads);
+    if (small) {
+        hipLaunchKernelGGL(post_kernel<true>, grid, block, lds, st, q);
+    } else {
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)post_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(post_kernel<false>, grid, block, lds, st, q);
+    }
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
@@ -1089,11 +1322,48 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     if (need_ab) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
     rc = upload_tables(P, ws, need_ab ? seq2utt.data() : nullptr, num_seqs, st);
     if (rc) return rc;
-    g_tm.have_fwd = g_tm.have_post = false;
+    g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = false;
+    // Fork: zero-fill the gradient box on the side stream while the sweeps (which occupy only 2B
+    // workgroups) run; post_kernel then only scatters the K posteriors per row.
+    const bool overlap = grad && P.any_compact && !getenv("WF_NO_OVERLAP");
+    Side* side = nullptr;
     if ((rc = tm_record(0, st))) return rc;
     rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
     if (rc) return rc;
     if ((rc = tm_record(1, st))) return rc;
+    if (overlap) {
+        // forked after the gather: both are HBM-bound and would only slow each other down
+        if ((rc = side_get(&side))) return rc;
+        HIP_TRY(hipEventRecord(side->fork, st));
+        HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        if ((rc = tm_record(5, side->stream))) return rc;
+        if (strideT == V && strideB == (int64_t)Tmax * V) {
+            const size_t n = (size_t)num_seqs * Tmax * V;
+            if (((uintptr_t)grad & 15) == 0 && !getenv("WF_ZERO_MEMSET")) {
+                const size_t n4 = n / 4;
+                // Size the grid so that the fill ends about when the sweeps do (~0.28 us per frame step,
+                // ~80 GB/s of streaming stores per workgroup): more workgroups than that only steal
+                // issue slots and memory-queue space from the latency-bound sweep workgroups
+                // (measured on cfg3: 32-64 blocks -> sweep 140 us; 1024 blocks -> 172 us).
+                int want = (int)((double)n * 4.0 / (std::max(P.Tlong, 1) * 0.28e-6) / 80e9) + 1;
+                want = std::max(32, std::min(want, 2048));
+                if (getenv("WF_ZERO_BLOCKS")) want = atoi(getenv("WF_ZERO_BLOCKS"));
+                const int blocks = (int)std::min<size_t>((n4 + 255) / 256, (size_t)want);
+                hipLaunchKernelGGL(zero_flat_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, side->stream,
+                                   (float4*)grad, n4, grad + n4 * 4, (int)(n - n4 * 4));
+                HIP_TRY(hipGetLastError());
+            } else {
+                HIP_TRY(hipMemsetAsync(grad, 0, sizeof(float) * n, side->stream));
+            }
+        } else {
+            ZeroArgs z{grad, strideB, strideT, V};
+            hipLaunchKernelGGL(zero_kernel, dim3(Tmax, num_seqs), dim3(256), 0, side->stream, z);
+            HIP_TRY(hipGetLastError());
+        }
+        if ((rc = tm_record(6, side->stream))) return rc;
+        g_tm.have_zero = g_tm.on;
+        HIP_TRY(hipEventRecord(side->join, side->stream));
+    }
     SweepCfg c = sweep_config(P, ab);
     SweepArgs a{};
     a.blob = (const int32_t*)graph_dev; a.utt = (const int64_t*)(ws + P.off_utt);
@@ -1110,8 +1380,9 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     if ((rc = tm_record(2, st))) return rc;
     g_tm.have_fwd = g_tm.on;
     if (grad) {
+        if (overlap) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
         if ((rc = tm_record(3, st))) return rc;
-        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, st);
+        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st);
         if (rc) return rc;
         if ((rc = tm_record(4, st))) return rc;
         g_tm.have_post = g_tm.on;
@@ -1119,13 +1390,13 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     return WF_OK;
 }
 
-extern "C" int wf_timing_enable(int on) { g_tm.on = on != 0; g_tm.have_fwd = g_tm.have_post = false; return WF_OK; }
+extern "C" int wf_timing_enable(int on) { g_tm.on = on != 0; g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = false; return WF_OK; }
 
-// ms[0..2] = gather, sweep, post kernel time of the last timed call(s); -1 where not measured.
+// ms[0..3] = gather, sweep, post, zero-fill kernel time of the last timed call(s); -1 = not measured.
 // Synchronises on the recorded events (a measurement aid, not part of the hot path).
 extern "C" int wf_timing_read(float* ms) {
     if (!ms) return wf_fail(WF_EINVAL, "wf_timing_read: null");
-    ms[0] = ms[1] = ms[2] = -1.f;
+    ms[0] = ms[1] = ms[2] = ms[3] = -1.f;
     if (g_tm.have_fwd) {
         HIP_TRY(hipEventSynchronize(g_tm.ev[2]));
         HIP_TRY(hipEventElapsedTime(&ms[0], g_tm.ev[0], g_tm.ev[1]));
@@ -1134,6 +1405,10 @@ extern "C" int wf_timing_read(float* ms) {
     if (g_tm.have_post) {
         HIP_TRY(hipEventSynchronize(g_tm.ev[4]));
         HIP_TRY(hipEventElapsedTime(&ms[2], g_tm.ev[3], g_tm.ev[4]));
+    }
+    if (g_tm.have_zero) {
+        HIP_TRY(hipEventSynchronize(g_tm.ev[6]));
+        HIP_TRY(hipEventElapsedTime(&ms[3], g_tm.ev[5], g_tm.ev[6]));
     }
     return WF_OK;
 }
@@ -1153,7 +1428,7 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     (void)dbl; (void)tot;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = tm_record(3, st))) return rc;
-    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, st);
+    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, false, st);
     if (rc) return rc;
     if ((rc = tm_record(4, st))) return rc;
     g_tm.have_post = g_tm.on;
