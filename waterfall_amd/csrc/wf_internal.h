@@ -74,5 +74,6 @@ enum {
     WF_U_S = 8, WF_U_A = 9, WF_U_K = 10, WF_U_DIRECT = 11, WF_U_MAXLABDEG = 12,
     WF_U_LAB_OFF = 13, WF_U_LAB_SRC = 14, WF_U_LAB_DST = 15, WF_U_LAB_COL = 16, WF_U_LAB_W = 17,
     WF_U_LABELS = 18,
+    WF_U_OFFS = 19,  // element offset of this utterance's per-frame offset rows (T+1 doubles)
     WF_U_WORDS = 24,
 };

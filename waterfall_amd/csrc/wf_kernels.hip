@@ -97,6 +97,9 @@ struct SweepArgs {
     void* beta;
     void* tot;     // float[B] (double[B] for tot-only + double acc)
     double* totd;  // workspace copy of tot in fp64 for post_kernel (M_FB), may be null
+    double* aoff;  // per-frame offsets of the renormalised fp32 alpha rows (register sweep, M_FB)
+    double* boff;
+    double* tot2;  // tot in log2 units (quad sweep -> post kernels)
     int32_t* bp;   // viterbi back-pointers, arena int32: [utt](T x S)
     int32_t* fin_arc;  // viterbi: best final arc per utterance [B]
     int chunk;     // frames per emission chunk (ESTAGE)
@@ -105,6 +108,7 @@ struct SweepArgs {
     int arcs_lds_words;  // words reserved for the LDS copy of the CSR arrays
     int hcap;      // heavy states reduced per cooperative round (sizes the LDS reduction scratch)
     int tot_double;
+    int ablate;    // measurement aid (WF_SWEEP_PROFILE=1 sets bit 8): workgroup 0 prints its cycles per frame step
 };
 
 // arc accessors: CSR arrays either in LDS (packed 16+16) or in global memory
@@ -389,38 +393,104 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// register-resident sweep: the fast path for graphs whose states have at most WF_REG_DEG arcs on
-// the swept side (every numerator topo o transcript) plus at most one high-degree
-// state (state 0 of a topology used as denominator).
+// register-resident "quad" sweep: the fast path for graphs whose states have at most WF_REG_DEG (4)
+// arcs on the swept side (every numerator topo o transcript) plus at most one
+// high-degree state (state 0 of a topology used as denominator).
 //
-// The graph does not change from frame to frame, so every lane loads the (src|column, weight)
-// descriptors of its state's arcs into VGPRs once.  A frame step is then: WF_REG_DEG independent
-// LDS reads of alpha, the adds, max, WF_REG_DEG v_exp, one v_log, one LDS write, one barrier.
-// Emissions are prefetched kPD frames ahead by the lane that will use them, straight into a
-// register ring (the frame loop is unrolled kPD times so the ring is statically indexed).
+// Measured on MI355X: a lone wavefront issues about one instruction every 4-5 cycles whatever its
+// kind, so the latency of a frame step is (instructions per wave) x 4 + LDS round trip + barrier.
+// The step is therefore spread as thinly as possible: FOUR LANES PER STATE, one arc per lane.  The
+// graph does not change from frame to frame, so each lane keeps its arc's (src | column, weight) in
+// VGPRs; a step is one ds_read of alpha[src], one fma/add, a 2-step DPP quad max, v_exp, a 2-step DPP
+// quad sum, v_log, one ds_write by the quad's first lane, one s_barrier, and one coalesced store of
+// the alpha row.  Row / emission pointers advance incrementally in SGPRs.  Emissions are prefetched
+// kPD frames ahead by the lane that will use them into a register ring (the frame loop is unrolled
+// kPD times so the ring is statically indexed).
+//
+// Log semiring: fp32 in the log2 domain (v_exp/v_log are base 2) with renormalisation: LDS and the
+// stored rows hold alpha~ = alpha*log2(e) - c, where the workgroup-uniform fp64 offset c advances
+// once per group of kPD frames by the maximum of the last row, so the values that matter stay
+// within ~1e2 of zero and fp32 keeps ~1e-5 absolute precision (plain fp32 alpha of magnitude ~2500
+// drifts by 3e-3 over T = 500: DESIGN.md section 2).  Dead states hold -1e30 instead of -inf, which
+// removes every special case from the step (no NaN can arise).  c is stored once per group.
+// Tropical semiring: the same kernel with exact fp32 add/max in natural units (no scaling, no
+// renormalisation), ties -> lowest arc index, one back-pointer per lattice state.
 // ------------------------------------------------------------------------------------------
 constexpr int kPD = 8;
+constexpr float kBig = 1e30f;
+constexpr float kDead = -1e29f;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr double kLn2 = 0.6931471805599453;
 
-template <typename Acc, typename Sum, int MODE, int R, int HD>
-__global__ void __launch_bounds__(kMaxThreads) sweep_reg_kernel(SweepArgs p) {
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROWMASK, 0xf, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWMASK, 0xf, false);
+}
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E: every lane has a source, all four lanes get the result
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v));
+    return fmaxf(v, dpp_f<0x4E, 0xf>(v, v));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_f<0xB1, 0xf>(v, v);
+    return v + dpp_f<0x4E, 0xf>(v, v);
+}
+// full-wave reductions on the DPP network (row_shr:4, row_shr:8, row_bcast:15, row_bcast:31); the
+// result lands in lane 63 and is broadcast through an SGPR.  Lanes without a source keep `old`.
+__device__ __forceinline__ float wave_max(float v) {
+    v = quad_max(v);
+    v = fmaxf(v, dpp_f<0x114, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x118, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = quad_sum(v);
+    v += dpp_f<0x114, 0xf>(0.f, v);
+    v += dpp_f<0x118, 0xf>(0.f, v);
+    v += dpp_f<0x142, 0xa>(0.f, v);
+    v += dpp_f<0x143, 0xc>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_i<0xB1, 0xf>(v, v));
+    v = min(v, dpp_i<0x4E, 0xf>(v, v));
+    v = min(v, dpp_i<0x114, 0xf>(v, v));
+    v = min(v, dpp_i<0x118, 0xf>(v, v));
+    v = min(v, dpp_i<0x142, 0xa>(v, v));
+    v = min(v, dpp_i<0x143, 0xc>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int MODE, int R, int HD>
+__global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool TROP = (MODE == M_TOT_MAX || MODE == M_VITERBI);
+    constexpr bool LOGS = !TROP;
     constexpr int NDIR = (MODE == M_FB) ? 2 : 1;
-    constexpr int D = WF_REG_DEG;
     constexpr int HDN = HD > 0 ? HD : 1;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int slot = tid & 3, quad = tid >> 2, nq = nt >> 2;
     const int u = blockIdx.x / NDIR, dir = blockIdx.x % NDIR;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int fsa = (int)U[WF_U_FSA], T = (int)U[WF_U_T];
     const int32_t* blob = p.blob;
     const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
     const int S = I[WF_I_S], A = I[WF_I_A], K = I[WF_I_K], direct = I[WF_I_DIRECT];
+    const float escale = LOGS ? kLog2e : 1.f;
 
-    Acc* cur = (Acc*)smem;
-    Acc* nxt = cur + p.smax;
-    Acc* red = nxt + p.smax;             // [16][2]
-    int* red_arc = (int*)(red + 32);     // [16]
+    float* cur = (float*)smem;
+    float* nxt = cur + p.smax;
+    float* red = nxt + p.smax;             // [16][2]
+    int* red_arc = (int*)(red + 32);       // [16]
+    float* rmax = (float*)(red_arc + 16);  // [16] per-wave maxima for the renormalisation
 
     const int32_t* g_off = blob + I[dir ? WF_I_OUT_OFF : WF_I_IN_OFF];
     const int32_t* g_oth = blob + I[dir ? WF_I_OUT_DST : WF_I_IN_SRC];
@@ -431,22 +501,22 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_reg_kernel(SweepArgs p) {
     const int over = has_over ? I[dir ? WF_I_OVER_OUT : WF_I_OVER_IN] : -1;
     const bool has_arcs = A > 0;
 
-    // ---- arc descriptors -> registers (padding: weight -inf, a valid state, column 0)
-    int pk[R][D];
-    float w[R][D];
-    int aid[R][D];
+    // ---- this lane's arc of each of its states (padding: weight -1e30, source = the state itself)
+    int pk[R];
+    float w[R];
+    int aid[R];
+    bool writer[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int sidx = tid + r * nt;
+        const int sidx = quad + r * nq;
         int a0 = 0, deg = 0;
         if (sidx < S && sidx != over) { a0 = g_off[sidx]; deg = g_off[sidx + 1] - a0; }
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const bool valid = i < deg;
-            pk[r][i] = valid ? ((g_oth[a0 + i] & 0xffff) | (g_col[a0 + i] << 16)) : 0;
-            w[r][i] = valid ? g_w[a0 + i] : -INFINITY;
-            aid[r][i] = (valid && MODE == M_VITERBI) ? arc_id[a0 + i] : 0x7fffffff;
-        }
+        const bool valid = slot < deg;
+        const int a = a0 + slot;
+        pk[r] = valid ? ((g_oth[a] & 0xffff) | (g_col[a] << 16)) : (sidx < S ? sidx : 0);
+        w[r] = valid ? fmaxf(g_w[a] * escale, -kBig) : -kBig;
+        aid[r] = (valid && MODE == M_VITERBI) ? arc_id[a] : 0x7fffffff;
+        writer[r] = slot == 0 && sidx < S && sidx != over;
     }
     int hpk[HDN];
     float hw[HDN];
@@ -459,7 +529,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_reg_kernel(SweepArgs p) {
             const int a = h0 + tid + j * nt;
             const bool valid = HD > 0 && a < h1;
             hpk[j] = valid ? ((g_oth[a] & 0xffff) | (g_col[a] << 16)) : 0;
-            hw[j] = valid ? g_w[a] : -INFINITY;
+            hw[j] = valid ? fmaxf(g_w[a] * escale, -kBig) : -kBig;
             haid[j] = (valid && MODE == M_VITERBI) ? arc_id[a] : 0x7fffffff;
         }
     }
@@ -473,136 +543,175 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_reg_kernel(SweepArgs p) {
         ebase = p.E + U[WF_U_E];
         epitch = K;
     }
-    auto frame_of = [&](int step) { return dir ? (T - 1 - step) : step; };
-    Acc* arena = (Acc*)(dir ? p.beta : p.alpha) + U[dir ? WF_U_BETA : WF_U_ALPHA];
-
-    {
-        const float* fb = (const float*)(blob + I[TROP ? WF_I_FINB_MAX : WF_I_FINB_LOG]);
-        for (int s = tid; s < S; s += nt) {
-            Acc v = dir ? (Acc)fb[s] : (s == 0 ? (Acc)0 : neg_inf<Acc>());
-            cur[s] = v;
-            if (MODE == M_FB) arena[(int64_t)(dir ? T : 0) * S + s] = v;
-        }
-    }
-
-    // ---- emission ring
-    float er[kPD][R * D];
-    float her[kPD][HDN];
     // Loads are unconditional (a select around a load makes hipcc branch and drain vmcnt per element):
     // steps past the end re-read the last frame, and a graph without arcs / an empty segment reads
     // the blob header through a zero pitch.
     if (!has_arcs || T == 0) { ebase = (const float*)blob; epitch = 0; }
     const int last_step = max(T - 1, 0);
-#define WF_LOAD_FRAME(STEP, SLOT)                                                          \
+    const int64_t estep = dir ? -epitch : epitch;
+    const float* eload = ebase + (int64_t)(dir ? last_step : 0) * epitch;   // row of load index 0
+
+    float* arena = (float*)(dir ? p.beta : p.alpha) + U[dir ? WF_U_BETA : WF_U_ALPHA];
+    double* goff = (MODE == M_FB) ? (dir ? p.boff : p.aoff) + U[WF_U_OFFS] : nullptr;
+    double coff = 0.0;   // current offset c (log2 units)
+
+    {
+        const float* fb = (const float*)(blob + I[TROP ? WF_I_FINB_MAX : WF_I_FINB_LOG]);
+        for (int s = tid; s < S; s += nt) {
+            float v;
+            if (dir) { const float f = fb[s]; v = (f == -INFINITY) ? -kBig : f * escale; }
+            else v = (s == 0) ? 0.f : -kBig;
+            cur[s] = v;
+            if (MODE == M_FB) arena[(int64_t)(dir ? T : 0) * S + s] = v;
+        }
+    }
+    // row written by step 0: forward alpha_1, backward beta_{T-1}; then +-S per step
+    float* srow = arena + (int64_t)(dir ? (T - 1) : 1) * S;
+    const int64_t sstep = dir ? -(int64_t)S : (int64_t)S;
+    int32_t* bprow = (MODE == M_VITERBI) ? p.bp + U[WF_U_ALPHA] : nullptr;
+
+    // ---- emission ring
+    float er[kPD][R];
+    float her[kPD][HDN];
+#define WF_LOAD_FRAME(SLOT)                                                                \
     do {                                                                                   \
-        const float* row_ = ebase + (int64_t)frame_of(min((STEP), last_step)) * epitch;    \
-        _Pragma("unroll") for (int r = 0; r < R; ++r)                                      \
-            _Pragma("unroll") for (int i = 0; i < D; ++i)                                  \
-                er[SLOT][r * D + i] = row_[(pk[r][i] >> 16) & 0xffff];                     \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) er[SLOT][r] = eload[(pk[r] >> 16) & 0xffff]; \
         if (HD > 0) {                                                                      \
-            _Pragma("unroll") for (int j = 0; j < HDN; ++j)                                \
-                her[SLOT][j] = row_[(hpk[j] >> 16) & 0xffff];                              \
+            _Pragma("unroll") for (int j = 0; j < HDN; ++j) her[SLOT][j] = eload[(hpk[j] >> 16) & 0xffff]; \
         }                                                                                  \
     } while (0)
 #pragma unroll
-    for (int k = 0; k < kPD; ++k) WF_LOAD_FRAME(k, k);
+    for (int k = 0; k < kPD; ++k) {
+        WF_LOAD_FRAME(k);
+        if (k < last_step) eload += estep;
+    }
     __syncthreads();
 
     // one frame step using (and then refilling) ring slot k; k is a constant after unrolling
     auto do_step = [&](const int step, const int k) __attribute__((always_inline)) {
-        // consume this frame's emissions (x = w + e, the lattice arc score in fp32) before the
-        // ring slot is refilled, so that the refill can land in the same registers
-        float x[R * D], hx[HDN];
+        // consume this frame's emissions (x = the lattice arc score) before the ring slot is refilled,
+        // so that the refill lands in the same registers
+        float x[R], hx[HDN];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                x[r * D + i] = w[r][i] + er[k][r * D + i];
-                asm volatile("" : "+v"(x[r * D + i]));   // pin: must not sink below the refill
-            }
+        for (int r = 0; r < R; ++r) {
+            x[r] = LOGS ? fmaf(er[k][r], kLog2e, w[r]) : w[r] + er[k][r];
+            asm volatile("" : "+v"(x[r]));   // pin: must not sink below the refill
+        }
 #pragma unroll
         for (int j = 0; j < HDN; ++j) {
-            hx[j] = hw[j] + her[k][j];
+            hx[j] = LOGS ? fmaf(her[k][j], kLog2e, hw[j]) : hw[j] + her[k][j];
             asm volatile("" : "+v"(hx[j]));
         }
         // keep the scheduler from hoisting the refill above the reads of the old values: that would
         // need a second register set and a copy + vmcnt(0) on the loop back-edge
         __builtin_amdgcn_sched_barrier(0);
-        WF_LOAD_FRAME(step + kPD, k);
-        const int f = frame_of(step);
-        Acc* store_row = (MODE == M_FB) ? arena + (int64_t)(dir ? f : f + 1) * S : nullptr;
-        int32_t* bp_row = (MODE == M_VITERBI) ? p.bp + U[WF_U_ALPHA] + (int64_t)f * S : nullptr;
-
-        // ---- the high-degree state: one arc (or HD arcs) per lane, wave + block reduction
+        WF_LOAD_FRAME(k);
+        if (step + kPD < last_step) eload += estep;
+        if (LOGS && k == 0) {
+            if (step >= kPD) {
+                // advance the offset by the maximum of the row finished at the end of the previous group
+                float m = rmax[0];
+                for (int i = 1; i < nw; ++i) m = fmaxf(m, rmax[i]);
+                if (m < kDead) m = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) x[r] -= m;
+#pragma unroll
+                for (int j = 0; j < HDN; ++j) hx[j] -= m;
+                coff += (double)m;
+            }
+            if (MODE == M_FB && tid == 0) goff[step / kPD] = coff;
+        }
+        float rowmax = -kBig;
+        // ---- the high-degree state: one arc (or HD arcs) per lane, wave (DPP) + block (LDS) reduction
         if (HD > 0 && has_over) {
-            Acc hv[HDN];
-            Acc m = neg_inf<Acc>();
+            float hv[HDN];
+            float m = -INFINITY;
             int barc = 0x7fffffff;
 #pragma unroll
             for (int j = 0; j < HDN; ++j) {
-                hv[j] = cur[hpk[j] & 0xffff] + (Acc)hx[j];
-                if (TROP) max_push(m, barc, hv[j], haid[j]);
-                else m = fmax(m, hv[j]);
+                hv[j] = cur[hpk[j] & 0xffff] + hx[j];
+                if (TROP) { if (hv[j] > m || (hv[j] == m && haid[j] < barc)) { m = hv[j]; barc = haid[j]; } }
+                else m = fmaxf(m, hv[j]);
             }
-            Sum sm = 0;
-            if (!TROP) {
+            const float M = wave_max(m);
+            float ssum = 0.f;
+            if (TROP) {
+                barc = wave_min_i(m == M ? barc : 0x7fffffff);
+            } else {
+                float sm = 0.f;
 #pragma unroll
-                for (int j = 0; j < HDN; ++j)
-                    sm += (m == neg_inf<Acc>()) ? (Sum)0 : fexp((Sum)(hv[j] - m));
+                for (int j = 0; j < HDN; ++j) sm += __builtin_amdgcn_exp2f(hv[j] - M);
+                ssum = wave_sum(sm);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                Acc m2 = shfl_xor(m, o);
-                if (TROP) { int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
-                else { Sum s2 = shfl_xor(sm, o); lse_merge(m, sm, m2, s2); }
-            }
+            float val = TROP ? M : M + __builtin_amdgcn_logf(ssum);
             if (nw > 1) {
-                if (lane == 0) { red[wave * 2] = m; red[wave * 2 + 1] = (Acc)sm; if (TROP) red_arc[wave] = barc; }
+                if (lane == 0) { red[wave * 2] = M; red[wave * 2 + 1] = ssum; if (TROP) red_arc[wave] = barc; }
                 __syncthreads();
                 if (tid == 0) {
-                    for (int x = 1; x < nw; ++x) {
-                        if (TROP) max_push(m, barc, red[x * 2], red_arc[x]);
-                        else lse_merge(m, sm, red[x * 2], (Sum)red[x * 2 + 1]);
+                    float Mx = red[0];
+                    for (int i = 1; i < nw; ++i) Mx = fmaxf(Mx, red[i * 2]);
+                    if (TROP) {
+                        int b = 0x7fffffff;
+                        for (int i = 0; i < nw; ++i) if (red[i * 2] == Mx) b = min(b, red_arc[i]);
+                        barc = b;
+                        val = Mx;
+                    } else {
+                        float st = 0.f;
+                        for (int i = 0; i < nw; ++i) st += red[i * 2 + 1] * __builtin_amdgcn_exp2f(red[i * 2] - Mx);
+                        val = Mx + __builtin_amdgcn_logf(st);
                     }
                 }
             }
             if (tid == 0) {
-                Acc val = TROP ? m : lse_value(m, sm);
                 nxt[over] = val;
-                if (MODE == M_FB) store_row[over] = val;
-                if (MODE == M_VITERBI) bp_row[over] = (m == neg_inf<Acc>()) ? -1 : barc;
+                if (MODE == M_FB) srow[over] = val;
+                if (MODE == M_VITERBI) bprow[over] = (val < kDead) ? -1 : barc;
+                rowmax = val;
             }
         }
-        // ---- ordinary states
+        // ---- ordinary states: one quad per state
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int sidx = tid + r * nt;
-            Acc v[D];
-#pragma unroll
-            for (int i = 0; i < D; ++i) v[i] = cur[pk[r][i] & 0xffff] + (Acc)x[r * D + i];
-            Acc val;
-            int barc = 0x7fffffff;
+            const int sidx = quad + r * nq;
+            const float v = cur[pk[r] & 0xffff] + x[r];
+            float val;
+            int barc = aid[r];
             if (TROP) {
-                val = neg_inf<Acc>();
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-                    if (v[i] > val) { val = v[i]; barc = aid[r][i]; }
+                // (max value, lowest arc id) over the quad: two symmetric exchange steps
+                float m = v;
+                {
+                    const float v2 = dpp_f<0xB1, 0xf>(m, m);
+                    const int a2 = dpp_i<0xB1, 0xf>(barc, barc);
+                    if (v2 > m || (v2 == m && a2 < barc)) { m = v2; barc = a2; }
+                }
+                {
+                    const float v2 = dpp_f<0x4E, 0xf>(m, m);
+                    const int a2 = dpp_i<0x4E, 0xf>(barc, barc);
+                    if (v2 > m || (v2 == m && a2 < barc)) { m = v2; barc = a2; }
+                }
+                val = m;
             } else {
-                Acc m = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
-                Sum sm = 0;
-#pragma unroll
-                for (int i = 0; i < D; ++i) sm += fexp((Sum)(v[i] - m));
-                val = (m == neg_inf<Acc>()) ? m : m + (Acc)flog(sm);
+                const float m = quad_max(v);
+                const float sm = quad_sum(__builtin_amdgcn_exp2f(v - m));
+                val = m + __builtin_amdgcn_logf(sm);
             }
-            if (sidx < S && sidx != over) {
+            if (writer[r]) {
                 nxt[sidx] = val;
-                if (MODE == M_FB) store_row[sidx] = val;
-                if (MODE == M_VITERBI) bp_row[sidx] = (val == neg_inf<Acc>()) ? -1 : barc;
+                if (MODE == M_FB) srow[sidx] = val;
+                if (MODE == M_VITERBI) bprow[sidx] = (val < kDead) ? -1 : barc;
             }
+            if (LOGS) rowmax = fmaxf(rowmax, val);
         }
+        if (LOGS && k == kPD - 1) {
+            const float wm = wave_max(rowmax);
+            if (lane == 0) rmax[wave] = wm;
+        }
+        srow += sstep;
+        if (MODE == M_VITERBI) bprow += S;
         __syncthreads();
-        Acc* t_ = cur; cur = nxt; nxt = t_;
+        float* t_ = cur; cur = nxt; nxt = t_;
     };
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     int t0 = 0;
     for (; t0 + kPD <= T; t0 += kPD) {   // full groups: no per-step guard, the ring stays in place
 #pragma unroll
@@ -612,39 +721,63 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_reg_kernel(SweepArgs p) {
     for (int k = 0; k < kPD; ++k)
         if (t0 + k < T) do_step(t0 + k, k);
 #undef WF_LOAD_FRAME
+    if ((p.ablate & 8) && blockIdx.x == 0 && tid == 0) {
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        printf("sweep_quad: T=%d nt=%d cycles/step=%.1f ns/step=%.1f clock=%.2f GHz\n", T, nt,
+               (double)(clk1 - clk0) / max(T, 1), (double)(rt1 - rt0) * 10.0 / max(T, 1),
+               (double)(clk1 - clk0) / ((double)(rt1 - rt0) * 10.0));
+    }
 
-    // ---- forward: total score over final arcs (block reduction)
+    // ---- forward: total score over final arcs (two block reductions; once per kernel)
     if (dir == 0) {
         const int NF = I[WF_I_NF];
         const int32_t* fsrc = blob + I[WF_I_FIN_SRC];
         const float* fw = (const float*)(blob + I[WF_I_FIN_W]);
         const int32_t* farc = blob + I[WF_I_FIN_ARC];
-        Acc m = neg_inf<Acc>();
-        Sum sm = 0;
+        float m = -INFINITY;
         int barc = 0x7fffffff;
         for (int i = tid; i < NF; i += nt) {
-            Acc v = cur[fsrc[i]] + (Acc)fw[i];
-            if (TROP) max_push(m, barc, v, farc[i]);
-            else lse_push(m, sm, v);
+            const float f = fw[i];
+            const float v = cur[fsrc[i]] + ((f == -INFINITY) ? -kBig : f * escale);
+            if (v > m || (v == m && farc[i] < barc)) { m = v; barc = farc[i]; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            Acc m2 = shfl_xor(m, o);
-            if (TROP) { int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
-            else { Sum s2 = shfl_xor(sm, o); lse_merge(m, sm, m2, s2); }
+        float M = wave_max(m);
+        if (lane == 0) red[wave] = M;
+        __syncthreads();
+        M = red[0];
+        for (int i = 1; i < nw; ++i) M = fmaxf(M, red[i]);
+        __syncthreads();
+        if (TROP) {
+            const int b = wave_min_i(m == M ? barc : 0x7fffffff);
+            if (lane == 0) red_arc[wave] = b;
+        } else {
+            float sm = 0.f;
+            for (int i = tid; i < NF; i += nt) {
+                const float f = fw[i];
+                sm += __builtin_amdgcn_exp2f(cur[fsrc[i]] + ((f == -INFINITY) ? -kBig : f * escale) - M);
+            }
+            sm = wave_sum(sm);
+            if (lane == 0) red[wave] = sm;
         }
-        if (lane == 0) { red[wave * 2] = m; red[wave * 2 + 1] = (Acc)sm; if (TROP) red_arc[wave] = barc; }
         __syncthreads();
         if (tid == 0) {
-            for (int x = 1; x < nw; ++x) {
-                if (TROP) max_push(m, barc, red[x * 2], red_arc[x]);
-                else lse_merge(m, sm, red[x * 2], (Sum)red[x * 2 + 1]);
+            const bool dead = !(M > kDead);   // also true for NF == 0 (M = -inf)
+            double out;
+            if (TROP) {
+                int b = red_arc[0];
+                for (int i = 1; i < nw; ++i) b = min(b, red_arc[i]);
+                out = dead ? (double)-INFINITY : (double)M;
+                if (MODE == M_VITERBI) p.fin_arc[u] = dead ? -1 : b;
+            } else {
+                float st = red[0];
+                for (int i = 1; i < nw; ++i) st += red[i];
+                const double tot2 = coff + (double)M + (double)__builtin_amdgcn_logf(st);
+                out = dead ? (double)-INFINITY : tot2 * kLn2;
+                if (MODE == M_FB && p.tot2) p.tot2[u] = dead ? (double)-INFINITY : tot2;
             }
-            Acc val = TROP ? m : lse_value(m, sm);
-            if (p.tot_double) ((double*)p.tot)[u] = (double)val;
-            else ((float*)p.tot)[u] = (float)val;
-            if (MODE == M_FB && p.totd) p.totd[u] = (double)val;
-            if (MODE == M_VITERBI) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
+            if (p.tot_double) ((double*)p.tot)[u] = out;
+            else ((float*)p.tot)[u] = (float)out;
+            if (MODE == M_FB && p.totd) p.totd[u] = out;
         }
     }
 }
@@ -692,14 +825,26 @@ struct PostArgs {
     const double* alpha;
     const double* beta;
     const double* totd;
+    const double* tot2;   // tot in log2 units (quad sweep), valid when ab_float
     float* grad;
     int Tmax, V, smax;
     int ecap;       // LDS floats reserved for the staged emission row (compact graphs), 0 = none
     int acap;       // LDS floats reserved for per-arc posteriors (arc-parallel mode), 0 = column loop
     int skip_zero;  // rows were zero-filled by zero_kernel already: only scatter the K values
     int fr;         // frames per workgroup
-    int ablate;     // debugging aid (WF_POST_ABLATE): skips parts of post_small_kernel to find its bottleneck
+    int ab_float;   // alpha/beta rows are renormalised fp32 (log2 units) + per-group fp64 offsets (quad sweep)
+    const double* aoff;
+    const double* boff;
 };
+
+// Quad-sweep rows are stored relative to a per-group offset: alpha row t (t >= 1) was produced by
+// forward step t-1, beta row t+1 (< T) by backward step T-2-t; rows 0 / T are the unscaled initial
+// vectors.  Returns off_a(t) + off_b(t+1) in log2 units.
+__device__ __forceinline__ double ab_offsets(const double* aoffs, const double* boffs, int t, int T) {
+    const double ga = t > 0 ? aoffs[(t - 1) / kPD] : 0.0;
+    const double gb = (t + 1 < T) ? boffs[(T - 2 - t) / kPD] : 0.0;
+    return ga + gb;
+}
 
 // zero n floats starting at p (4-byte aligned) with 16-byte stores where alignment allows
 __device__ __forceinline__ void zero_span(float* p, int n, int tid, int nt) {
@@ -768,6 +913,15 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     const int S = I[WF_I_S], A = I[WF_I_A], K = I[WF_I_K], direct = I[WF_I_DIRECT];
     const double* abase = p.alpha + U[WF_U_ALPHA];
     const double* bbase = p.beta + U[WF_U_BETA];
+    const float* abase_f = (const float*)p.alpha + U[WF_U_ALPHA];
+    const float* bbase_f = (const float*)p.beta + U[WF_U_BETA];
+    const bool abf = p.ab_float != 0;
+    // posterior = exp2(xs * (alpha + beta) + es * (w + e)): quad-sweep rows are already in log2 units
+    const float xs = abf ? 1.f : kLog2e, es = kLog2e;
+    const double* aoffs = p.aoff + U[WF_U_OFFS];
+    const double* boffs = p.boff + U[WF_U_OFFS];
+    auto ldA = [&](int64_t i) { return abf ? (double)abase_f[i] : abase[i]; };
+    auto ldB = [&](int64_t i) { return abf ? (double)bbase_f[i] : bbase[i]; };
     const float* ebase = direct ? p.lp + (int64_t)q * p.strideB + (int64_t)start * p.strideT : p.E + U[WF_U_E];
     const int64_t epitch = direct ? p.strideT : K;
     const bool stage_e = !direct && K <= p.ecap;
@@ -786,7 +940,7 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     float pe = 0.f;
     auto prefetch = [&](int t) {
         if (!SMALL || t < 0 || t >= T) return;
-        if (tid < S) { pa = abase[(int64_t)t * S + tid]; pb = bbase[(int64_t)(t + 1) * S + tid]; }
+        if (tid < S) { pa = ldA((int64_t)t * S + tid); pb = ldB((int64_t)(t + 1) * S + tid); }
         if (stage_e && tid < K) pe = ebase[(int64_t)t * epitch + tid];
     };
     prefetch(max(f0 - start, 0));
@@ -798,8 +952,7 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
             if (!p.skip_zero) zero_span(grow, V, tid, nt);
             continue;
         }
-        const double* arow = abase + (int64_t)t * S;
-        const double* brow = bbase + (int64_t)(t + 1) * S;
+        const int64_t arow = (int64_t)t * S, brow = (int64_t)(t + 1) * S;
         const float* erow = ebase + (int64_t)t * epitch;
         // reference point: the best alpha of this frame, so that both LDS vectors hold small numbers
         double mx = (double)-INFINITY;
@@ -809,7 +962,8 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
             if (stage_e && tid < K) le[tid] = pe;
             prefetch(t + 1 < T && f + 1 < f1 ? t + 1 : -1);
         } else {
-            for (int s = tid; s < S; s += nt) mx = fmax(mx, arow[s]);
+            if (!abf)
+                for (int s = tid; s < S; s += nt) mx = fmax(mx, ldA(arow + s));
             if (stage_e)
                 for (int k = tid; k < K; k += nt) le[k] = erow[k];
         }
@@ -823,13 +977,17 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
         __syncthreads();
         double a_ref = wmax[0];
         for (int x = 1; x < nwv; ++x) a_ref = fmax(a_ref, wmax[x]);
-        const double b_ref = tot - a_ref;
+        double b_ref = tot - a_ref;
+        if (abf) {   // rows are already relative to their offsets: fold (off_a + off_b - tot) into alpha
+            a_ref = -(ab_offsets(aoffs, boffs, t, T) - p.tot2[u]);
+            b_ref = 0.0;
+        }
         if (SMALL) {
             if (tid < S) { la[tid] = (float)(ca - a_ref); lb[tid] = (float)(cb - b_ref); }
         } else {
             for (int s = tid; s < S; s += nt) {
-                la[s] = (float)(arow[s] - a_ref);
-                lb[s] = (float)(brow[s] - b_ref);
+                la[s] = (float)(ldA(arow + s) - a_ref);
+                lb[s] = (float)(ldB(brow + s) - b_ref);
             }
         }
         __syncthreads();
@@ -840,7 +998,7 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
             for (int a = tid; a < A; a += nt) {
                 const int c = lcol[a];
                 const float e = stage_e ? le[c] : erow[c];
-                lpost[a] = fexp(la[lsrc[a]] + (lw[a] + e) + lb[ldst[a]]);
+                lpost[a] = __builtin_amdgcn_exp2f((la[lsrc[a]] + lb[ldst[a]]) * xs + (lw[a] + e) * es);
             }
             __syncthreads();
             for (int k = tid; k < K; k += nt) {
@@ -855,8 +1013,7 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
                 const float e = stage_e ? le[k] : erow[k];
                 float acc = 0.f;
                 for (int a = a0; a < a1; ++a) {
-                    float x = la[lsrc[a]] + (lw[a] + e) + lb[ldst[a]];
-                    acc += fexp(x);   // exp(-inf) = 0 for dead states
+                    acc += __builtin_amdgcn_exp2f((la[lsrc[a]] + lb[ldst[a]]) * xs + (lw[a] + e) * es);   // 0 for dead states
                 }
                 grow[direct ? k : labels[k]] = gs * acc;
             }
@@ -887,9 +1044,10 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     const double tot = p.totd[u];
     if (t < 0 || t >= T || tot == (double)-INFINITY) return;
     const int S = (int)U[WF_U_S], A = (int)U[WF_U_A], K = (int)U[WF_U_K];
-    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
-    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    const float* arow = (const float*)p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const float* brow = (const float*)p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
     const float* erow = p.E + U[WF_U_E] + (int64_t)t * K;
+    const float cst = (float)(ab_offsets(p.aoff + U[WF_U_OFFS], p.boff + U[WF_U_OFFS], t, T) - p.tot2[u]);
     const int32_t* loff = p.blob + U[WF_U_LAB_OFF];
     const int32_t* lsrc = p.blob + U[WF_U_LAB_SRC];
     const int32_t* ldst = p.blob + U[WF_U_LAB_DST];
@@ -900,7 +1058,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
 
     // ---- batch 2: all independent loads (indices clamped so that no load is conditional)
-    double av[kPS], bv[kPS];
+    float av[kPS], bv[kPS];
     float ev[kPS];
     int asrc[kPS], adst[kPS], acol[kPS];
     float aw[kPS];
@@ -914,23 +1072,17 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
         const int a = min(lane + i * 64, A - 1);
         asrc[i] = lsrc[a]; adst[i] = ldst[a]; acol[i] = lcol[a]; aw[i] = lw[a];
     }
-    double mx = (double)-INFINITY;
-#pragma unroll
-    for (int i = 0; i < kPS; ++i) mx = fmax(mx, av[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, shfl_xor(mx, o));
-    const double a_ref = mx, b_ref = tot - mx;
 #pragma unroll
     for (int i = 0; i < kPS; ++i) {
         const int s = lane + i * 64;
-        if (s < S) { la[s] = (float)(av[i] - a_ref); lb[s] = (float)(bv[i] - b_ref); }
+        if (s < S) { la[s] = av[i] + cst; lb[s] = bv[i]; }
         if (s < K) le[s] = ev[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kPS; ++i) {
         const int a = lane + i * 64;
-        if (a < A) lpost[a] = fexp(la[asrc[i]] + (aw[i] + le[acol[i]]) + lb[adst[i]]);
+        if (a < A) lpost[a] = __builtin_amdgcn_exp2f(la[asrc[i]] + (aw[i] + le[acol[i]]) * kLog2e + lb[adst[i]]);
     }
     __syncthreads();
     // per-column sums in arc order (bit-stable)
@@ -938,11 +1090,8 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
         const int a0 = loff[k], a1 = loff[k + 1];
         const int lab = labels[k];
         float acc = 0.f;
-        if (p.ablate & 2) acc = lpost[a0];
-        else
-            for (int a = a0; a < a1; ++a) acc += lpost[a];
-        if (!(p.ablate & 1)) grow[lab] = gs * acc;
-        else if (acc == 123.456f) grow[lab] = acc;
+        for (int a = a0; a < a1; ++a) acc += lpost[a];
+        grow[lab] = gs * acc;
     }
 }
 
@@ -987,7 +1136,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
     int B = 0;
-    size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_totd = 0, off_E = 0, off_alpha = 0, off_beta = 0,
+    size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_totd = 0, off_tot2 = 0, off_aoff = 0, off_boff = 0, off_E = 0, off_alpha = 0, off_beta = 0,
            off_bp = 0, off_finarc = 0, total = 0;
     std::vector<int64_t> utt;  // B * WF_U_WORDS
     int smax = 0, kmax_compact = 0, kmax = 0, amax = 0, hmax = 0, maxlabdeg = 0;
@@ -1028,6 +1177,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         int64_t* U = &P->utt[(size_t)i * WF_U_WORDS];
         U[WF_U_FSA] = g; U[WF_U_SEQ] = b; U[WF_U_START] = st; U[WF_U_T] = T;
         U[WF_U_ALPHA] = nab; U[WF_U_BETA] = nab; U[WF_U_E] = nE; U[WF_U_ROW0] = row0;
+        U[WF_U_OFFS] = row0 + i;   // sum of (T+1) over the utterances before this one
         U[WF_U_S] = I[WF_I_S]; U[WF_U_A] = I[WF_I_A]; U[WF_U_K] = I[WF_I_K]; U[WF_U_DIRECT] = I[WF_I_DIRECT];
         U[WF_U_MAXLABDEG] = I[WF_I_MAXLAB_DEG];
         U[WF_U_LAB_OFF] = I[WF_I_LAB_OFF]; U[WF_U_LAB_SRC] = I[WF_I_LAB_SRC]; U[WF_U_LAB_DST] = I[WF_I_LAB_DST];
@@ -1056,10 +1206,13 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     P->off_gscale = o; o = align_up(o + sizeof(float) * B, 256);
     P->off_finarc = o; o = align_up(o + sizeof(int32_t) * B, 256);
     P->off_totd = o; o = align_up(o + sizeof(double) * B, 256);
+    P->off_tot2 = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
     if (mode == 0) {
         P->off_alpha = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
         P->off_beta = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
+        P->off_aoff = o; o = align_up(o + sizeof(double) * (size_t)(row0 + B), 256);
+        P->off_boff = o; o = align_up(o + sizeof(double) * (size_t)(row0 + B), 256);
     } else if (mode == 2) {
         P->off_bp = o; o = align_up(o + sizeof(int32_t) * (size_t)nab, 256);
     }
@@ -1159,45 +1312,56 @@ int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
     return WF_OK;
 }
 
-// ---- register-resident sweep: eligibility and launch
+// ---- register-resident quad sweep: eligibility and launch
 struct RegCfg {
     bool ok = false;
     int threads = 0, R = 1, HD = 0, smax = 0;
     size_t lds = 0;
 };
 
-RegCfg reg_config(const Plan& P, size_t acc_bytes, bool both_dirs) {
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+RegCfg reg_config(const Plan& P, bool both_dirs) {
     RegCfg c;
-    if (getenv("WF_NO_REG_SWEEP")) return c;
-    if (!P.arcs_lds_ok || P.smax > 2 * kMaxThreads || !P.reg_ok_in || (both_dirs && !P.reg_ok_out)) return c;
-    c.R = P.smax <= kMaxThreads ? 1 : 2;
-    c.threads = std::max(64, (int)align_up((P.smax + c.R - 1) / c.R, 64));
+    static const int no_reg = env_int("WF_NO_REG_SWEEP", 0);
+    if (no_reg) return c;
+    if (!P.arcs_lds_ok || P.smax > kMaxThreads || !P.reg_ok_in || (both_dirs && !P.reg_ok_out)) return c;
+    // four lanes per state; R states per quad once 4*S exceeds the workgroup
+    c.R = P.smax * 4 <= kMaxThreads ? 1 : (P.smax * 2 <= kMaxThreads ? 2 : 4);
+    static const int force_r = env_int("WF_QUAD_R", 0);
+    if (force_r == 2 || force_r == 4) c.R = std::max(c.R, force_r);
+    c.threads = std::max(64, (int)align_up(4 * (size_t)((P.smax + c.R - 1) / c.R), 64));
     const int od = std::max(P.over_deg_in, both_dirs ? P.over_deg_out : 0);
     c.HD = (od + c.threads - 1) / c.threads;
-    if (c.HD > 2) return c;
+    if (c.HD > 2 || (c.R == 4 && c.HD > 0)) return c;   // R = 4 with a cooperative state would spill VGPRs
     c.smax = (int)align_up(P.smax, 4);
-    c.lds = 2 * (size_t)c.smax * acc_bytes + 32 * acc_bytes + 64;
+    c.lds = 2 * (size_t)c.smax * 4 + 32 * 4 + 64 + 64;
     c.ok = true;
     return c;
 }
 
-template <typename Acc, typename Sum, int MODE>
-int launch_sweep_reg(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
+template <int MODE>
+int launch_sweep_quad(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
     const int ndir = (MODE == M_FB) ? 2 : 1;
     dim3 grid(B * ndir), block(c.threads);
     a.smax = c.smax;
-#define WF_LAUNCH_REG(RR, HH)                                                                   \
-    hipLaunchKernelGGL((sweep_reg_kernel<Acc, Sum, MODE, RR, HH>), grid, block, c.lds, st, a)
-    if (c.R == 1) {
-        if (c.HD == 0) WF_LAUNCH_REG(1, 0);
-        else if (c.HD == 1) WF_LAUNCH_REG(1, 1);
-        else WF_LAUNCH_REG(1, 2);
-    } else {
-        if (c.HD == 0) WF_LAUNCH_REG(2, 0);
-        else if (c.HD == 1) WF_LAUNCH_REG(2, 1);
-        else WF_LAUNCH_REG(2, 2);
-    }
-#undef WF_LAUNCH_REG
+    static const int prof = env_int("WF_SWEEP_PROFILE", 0);
+    a.ablate = prof ? 8 : 0;
+#define WF_LAUNCH_QUAD(RR, HH) hipLaunchKernelGGL((sweep_quad_kernel<MODE, RR, HH>), grid, block, c.lds, st, a)
+#define WF_LAUNCH_QUAD_R(RR)                       \
+    do {                                           \
+        if (c.HD == 0) WF_LAUNCH_QUAD(RR, 0);      \
+        else if (c.HD == 1) WF_LAUNCH_QUAD(RR, 1); \
+        else WF_LAUNCH_QUAD(RR, 2);                \
+    } while (0)
+    if (c.R == 1) WF_LAUNCH_QUAD_R(1);
+    else if (c.R == 2) WF_LAUNCH_QUAD_R(2);
+    else WF_LAUNCH_QUAD_R(4);
+#undef WF_LAUNCH_QUAD_R
+#undef WF_LAUNCH_QUAD
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
@@ -1261,23 +1425,24 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
 
 int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                 int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
-                float* grad, bool skip_zero, hipStream_t st) {
+                float* grad, bool skip_zero, bool ab_float, hipStream_t st) {
     PostArgs q{};
+    q.ab_float = ab_float ? 1 : 0;
+    q.aoff = (const double*)(ws + P.off_aoff); q.boff = (const double*)(ws + P.off_boff);
     q.blob = (const int32_t*)graph_dev; q.utt = (const int64_t*)(ws + P.off_utt);
     q.seq2utt = (const int32_t*)(ws + P.off_seq2utt);
     q.gscale = gscale_dev;
     q.lp = lp; q.strideB = strideB; q.strideT = strideT; q.E = (const float*)(ws + P.off_E);
     q.alpha = (const double*)(ws + P.off_alpha); q.beta = (const double*)(ws + P.off_beta);
-    q.totd = (const double*)(ws + P.off_totd); q.grad = grad; q.Tmax = Tmax; q.V = V;
+    q.totd = (const double*)(ws + P.off_totd); q.tot2 = (const double*)(ws + P.off_tot2); q.grad = grad; q.Tmax = Tmax; q.V = V;
     q.smax = (int)align_up(P.smax, 4);
     q.ecap = (P.any_compact && P.kmax_compact <= 8192) ? (int)align_up(P.kmax_compact, 4) : 0;
     q.acap = (P.maxlabdeg > 8 && P.amax <= 8192) ? (int)align_up(P.amax, 4) : 0;
     q.skip_zero = skip_zero ? 1 : 0;
     size_t lds = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
-    if (skip_zero && !getenv("WF_NO_POST_SMALL") && P.all_compact && P.amax >= 1 && P.amax <= 64 * kPS && P.smax <= 64 * kPS &&
+    if (ab_float && skip_zero && !getenv("WF_NO_POST_SMALL") && P.all_compact && P.amax >= 1 && P.amax <= 64 * kPS && P.smax <= 64 * kPS &&
         P.kmax_compact <= 64 * kPS && q.ecap > 0) {
         q.acap = (int)align_up(P.amax, 4);
-        q.ablate = getenv("WF_POST_ABLATE") ? atoi(getenv("WF_POST_ABLATE")) : 0;
         size_t lds2 = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
         hipLaunchKernelGGL(post_small_kernel, dim3(Tmax, num_seqs), dim3(64), lds2, st, q);
         HIP_TRY(hipGetLastError());
@@ -1372,8 +1537,10 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     a.alpha = ws + P.off_alpha; a.beta = ws + P.off_beta; a.tot = tot; a.bp = nullptr; a.fin_arc = nullptr;
     a.totd = (double*)(ws + P.off_totd);
     a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
-    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, ab, need_ab);
-    if (rc_.ok) rc = need_ab ? launch_sweep_reg<double, float, M_FB>(rc_, a, B, st) : launch_sweep_reg<double, float, M_TOT_LOG>(rc_, a, B, st);
+    a.aoff = (double*)(ws + P.off_aoff); a.boff = (double*)(ws + P.off_boff);
+    a.tot2 = (double*)(ws + P.off_tot2);
+    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, need_ab);
+    if (rc_.ok) rc = need_ab ? launch_sweep_quad<M_FB>(rc_, a, B, st) : launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
     else if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);
     else rc = dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
     if (rc) return rc;
@@ -1382,7 +1549,7 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     if (grad) {
         if (overlap) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
         if ((rc = tm_record(3, st))) return rc;
-        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st);
+        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, rc_.ok, st);
         if (rc) return rc;
         if ((rc = tm_record(4, st))) return rc;
         g_tm.have_post = g_tm.on;
@@ -1428,7 +1595,8 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     (void)dbl; (void)tot;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = tm_record(3, st))) return rc;
-    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, false, st);
+    const bool ab_float = !dbl && reg_config(P, true).ok;   // same decision as the forward call made
+    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, false, ab_float, st);
     if (rc) return rc;
     if ((rc = tm_record(4, st))) return rc;
     g_tm.have_post = g_tm.on;
@@ -1460,9 +1628,9 @@ extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, cons
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
     a.tot = tot; a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap;
     a.tot_double = dbl ? 1 : 0;
-    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, ab, false);
-    if (rc_.ok) return (flags & WF_TROPICAL) ? launch_sweep_reg<float, float, M_TOT_MAX>(rc_, a, B, st)
-                                             : launch_sweep_reg<double, float, M_TOT_LOG>(rc_, a, B, st);
+    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, false);
+    if (rc_.ok) return (flags & WF_TROPICAL) ? launch_sweep_quad<M_TOT_MAX>(rc_, a, B, st)
+                                             : launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
     if (flags & WF_TROPICAL) return dbl ? launch_sweep<double, double, M_TOT_MAX>(c, a, B, st) : launch_sweep<float, float, M_TOT_MAX>(c, a, B, st);
     return dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
 }
@@ -1495,8 +1663,8 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
     a.tot = best_score; a.bp = (int32_t*)(ws + P.off_bp); a.fin_arc = (int32_t*)(ws + P.off_finarc);
     a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
-    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, ab, false);
-    if (rc_.ok) rc = launch_sweep_reg<float, float, M_VITERBI>(rc_, a, B, st);
+    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, false);
+    if (rc_.ok) rc = launch_sweep_quad<M_VITERBI>(rc_, a, B, st);
     else rc = dbl ? launch_sweep<double, double, M_VITERBI>(c, a, B, st) : launch_sweep<float, float, M_VITERBI>(c, a, B, st);
     if (rc) return rc;
     TraceArgs t{a.blob, a.utt, a.bp, a.fin_arc, nullptr, best_arcs, B, Tmax};
