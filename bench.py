@@ -114,16 +114,21 @@ class Workload:
                                     self.ws_bytes, C.c_void_p(stream)))
 
     # ---- algorithmic bytes (DESIGN.md "Kernels"): what each kernel must move, per batch --------
-    def kernel_bytes(self):
+    def kernel_bytes(self, lin=False):
         V = self.V
-        gather = 8 * self.compact_K_frames                      # read 4 B + write 4 B per gathered element
-        sweep = 2 * 4 * self.K_frames + 2 * 8 * self.S_frames   # emissions read by both sweeps + alpha/beta rows out
+        if lin:   # linear-domain sweep: emissions are staged as fp64 probabilities
+            gather = (4 + 8) * self.K_frames + 4 * self.compact_K_frames   # read lp, write P (fp64) [+ raw E for compact graphs]
+            sweep = 2 * 8 * self.K_frames + 2 * 8 * self.S_frames       # P read by both sweeps + alpha/beta rows out
+        else:
+            gather = 8 * self.compact_K_frames                      # read 4 B + write 4 B per gathered element
+            sweep = 2 * 4 * self.K_frames + 2 * 8 * self.S_frames   # emissions read by both sweeps + alpha/beta rows out
+        check = 2 * 8 * self.S_frames                           # alpha and beta rows read once more
         zero = 4 * V * self.B * self.T                          # zero-fill of the gradient box (side stream)
         direct_K_frames = self.K_frames - self.compact_K_frames
         post = 2 * 8 * self.S_frames + 4 * self.K_frames + 4 * self.compact_K_frames + 4 * direct_K_frames  # alpha/beta in + emissions in + values out
         # SURVEY.md 8(d) whole-path figure: 4V (lp row) + 4V (grad row) + 8S (alpha spill + reload) per frame
         path = (8 * V) * self.frames + 8 * self.S_frames
-        return {"gather": gather, "sweep": sweep, "post": post, "zero": zero, "path_survey_8d": path}
+        return {"gather": gather, "sweep": sweep, "post": post, "zero": zero, "check": check, "path_survey_8d": path}
 
 
 def time_steps(wl, steps, warmup, dist, stream, fused_buf):
@@ -155,14 +160,14 @@ def kernel_times(wl, stream, reps=20):
     the launch stream around each kernel."""
     lib = _lib.lib()
     lib.wf_timing_enable(1)
-    acc = np.zeros(4)
-    ms = (C.c_float * 4)()
+    acc = np.zeros(5)
+    ms = (C.c_float * 8)()
     for _ in range(reps):
         wl.step(stream)
         _lib.check(lib.wf_timing_read(ms))
-        acc += np.array(list(ms))
+        acc += np.array(list(ms)[:5])
     lib.wf_timing_enable(0)
-    return dict(zip(("gather", "sweep", "post", "zero"), (acc / reps).tolist()))
+    return dict(zip(("gather", "sweep", "post", "zero", "check"), (acc / reps).tolist()))
 
 
 def cpu_baseline(wl, budget_s=12.0):
@@ -264,7 +269,7 @@ def main():
     }
     if rank == 0:
         kt = kernel_times(wl, stream)
-        kb = wl.kernel_bytes()
+        kb = wl.kernel_bytes(lin=kt["check"] >= 0)
         dom = max(kt, key=lambda k: kt[k])
         ach = kb[dom] / (kt[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,

@@ -140,8 +140,9 @@ int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt
 /* ---- measurement aid (no counterpart in the reference) ------------------------------------------
  * wf_timing_enable(1): the following wf_fb_logsum / wf_fb_backward calls of this host thread record
  * HIP events on the caller's stream around each kernel; wf_timing_read() waits for them and
- * returns ms[4] = {emission gather, alpha/beta sweep, posterior/gradient, gradient zero-fill (runs on
- * a side stream concurrently with the sweep)} kernel times (-1 = not run).  Used by bench.py for the per-kernel roofline numbers.                                    */
+ * returns ms[5] = {emission gather, alpha/beta sweep, posterior/gradient, gradient zero-fill (runs on
+ * a side stream concurrently with the sweep), row check + fallback} kernel times in ms (-1 = not run).
+ * Used by bench.py for the per-kernel roofline numbers.                                          */
 int wf_timing_enable(int on);
 int wf_timing_read(float* ms);
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <climits>
 #include <cstring>
 #include <deque>
 #include <numeric>
@@ -83,6 +84,8 @@ int plan_fsa(const wf_graph_host* gh, int g, FsaPlan* p, std::vector<int>* label
     w += 3 * pad4(p->NF);                       // fin_src, fin_w, fin_arc
     w += 2 * pad4(S);                           // heavy_in, heavy_out (upper bound)
     w += 2 * pad4(S) + pad4(p->A + p->NF);      // finb_log, finb_max, arc_src
+    if (S - 1 <= 64 * WF_BAND_MAX_R)   // banded form is only built for graphs one wavefront can hold
+        w += pad4(S) + 2 * pad4((size_t)S * (WF_BAND_MAX_BW + 1) * WF_BAND_MAX_M * 2);   // order + two tables (upper bound)
     p->words = w;
     return WF_OK;
 }
@@ -244,6 +247,75 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
                 memcpy(&B[o_fm + s], &fm, 4);
             }
             for (int a = 0; a < A + p.NF; ++a) B[o_as + a] = arcs[4 * a];
+        }
+        // ---- fewest frames any accepted path needs (BFS over emitting arcs from the start state)
+        {
+            std::vector<int> dist(S, -1);
+            std::vector<char> fin_src(S, 0);
+            for (int a : p.fin) fin_src[arcs[4 * a]] = 1;
+            const int32_t* ooff = B + I[WF_I_OUT_OFF];
+            const int32_t* odst = B + I[WF_I_OUT_DST];
+            std::deque<int> q;
+            dist[0] = 0; q.push_back(0);
+            int minlen = INT32_MAX;
+            while (!q.empty()) {
+                int s = q.front(); q.pop_front();
+                if (fin_src[s]) { minlen = dist[s]; break; }   // BFS: the first final-capable state is the nearest
+                for (int e = ooff[s]; e < ooff[s + 1]; ++e)
+                    if (dist[odst[e]] < 0) { dist[odst[e]] = dist[s] + 1; q.push_back(odst[e]); }
+            }
+            I[WF_I_MINLEN] = minlen;
+        }
+        // ---- banded form: Kahn topological order (FIFO, self-loops ignored) of the non-final states
+        {
+            const int Sn = S - 1;   // the super-final state has no emitting arcs
+            I[WF_I_BAND_BW] = -1; I[WF_I_BAND_M] = 0;
+            std::vector<int> indeg(Sn, 0), order, pos(Sn, -1);
+            const int32_t* ooff = B + I[WF_I_OUT_OFF];
+            const int32_t* odst = B + I[WF_I_OUT_DST];
+            for (int s = 0; s < Sn; ++s)
+                for (int e = ooff[s]; e < ooff[s + 1]; ++e)
+                    if (odst[e] != s) indeg[odst[e]]++;
+            std::deque<int> q;
+            if (Sn <= 64 * WF_BAND_MAX_R)
+                for (int s = 0; s < Sn; ++s) if (indeg[s] == 0) q.push_back(s);
+            while (!q.empty()) {
+                int s = q.front(); q.pop_front();
+                pos[s] = (int)order.size(); order.push_back(s);
+                for (int e = ooff[s]; e < ooff[s + 1]; ++e)
+                    if (odst[e] != s && --indeg[odst[e]] == 0) q.push_back(odst[e]);
+            }
+            if ((int)order.size() == Sn && Sn >= 1 && Sn <= 64 * WF_BAND_MAX_R) {
+                int bw = 0;
+                for (int a : p.em) bw = std::max(bw, pos[arcs[4 * a + 1]] - pos[arcs[4 * a]]);
+                // arcs per (destination position, distance) cell
+                int m = 0;
+                if (bw <= WF_BAND_MAX_BW) {
+                    std::vector<int> cnt((size_t)Sn * (bw + 1), 0);
+                    for (int a : p.em) m = std::max(m, ++cnt[(size_t)pos[arcs[4 * a + 1]] * (bw + 1) + (pos[arcs[4 * a + 1]] - pos[arcs[4 * a]])]);
+                }
+                if (bw <= WF_BAND_MAX_BW && m <= WF_BAND_MAX_M) {
+                    m = std::max(m, 1);
+                    const size_t cells = (size_t)Sn * (bw + 1) * m;
+                    int o_ord = take(Sn), o_f = take(cells * 2), o_b = take(cells * 2);
+                    I[WF_I_BAND_BW] = bw; I[WF_I_BAND_M] = m; I[WF_I_BAND_ORDER] = o_ord; I[WF_I_BANDF] = o_f; I[WF_I_BANDB] = o_b;
+                    memcpy(B + o_ord, order.data(), sizeof(int) * Sn);
+                    // empty cells: column 0, weight -inf (probability 0)
+                    float ninf = -INFINITY; int32_t nbits; memcpy(&nbits, &ninf, 4);
+                    for (size_t c = 0; c < cells; ++c) { B[o_f + 2 * c] = 0; B[o_f + 2 * c + 1] = nbits; B[o_b + 2 * c] = 0; B[o_b + 2 * c + 1] = nbits; }
+                    std::vector<int> fillf((size_t)Sn * (bw + 1), 0), fillb((size_t)Sn * (bw + 1), 0);
+                    for (int a : p.em) {
+                        const int ps = pos[arcs[4 * a]], pd = pos[arcs[4 * a + 1]], d = pd - ps;
+                        const int col = col_of(arcs[4 * a + 2]);
+                        size_t cf = (size_t)pd * (bw + 1) + d;
+                        size_t ef = cf * m + fillf[cf]++;
+                        B[o_f + 2 * ef] = col; B[o_f + 2 * ef + 1] = arcs[4 * a + 3];
+                        size_t cb = (size_t)(Sn - 1 - ps) * (bw + 1) + d;
+                        size_t eb = cb * m + fillb[cb]++;
+                        B[o_b + 2 * eb] = col; B[o_b + 2 * eb + 1] = arcs[4 * a + 3];
+                    }
+                }
+            }
         }
         if (cur * 4 > need) return wf_fail(WF_ENOSPC, "internal: blob overflow");
     }

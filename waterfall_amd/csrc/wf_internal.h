@@ -6,7 +6,7 @@
 
 #define WF_BLOB_MAGIC 0x31474657  // "WFG1"
 #define WF_HDR_WORDS 8
-#define WF_INFO_WORDS 40
+#define WF_INFO_WORDS 48
 // A state whose in-degree (forward sweep) or out-degree (backward sweep) exceeds this is reduced
 // cooperatively by the whole workgroup instead of by one lane.
 #define WF_HEAVY_DEG 16
@@ -58,7 +58,21 @@ enum {
     WF_I_NOVER_OUT = 36,   // same for out-degree
     WF_I_OVER_OUT = 37,
     WF_I_LAB_COL = 38,     // [A] column of every column-sorted arc
+    WF_I_MINLEN = 39,      // fewest emitting arcs on any start -> final path (INT32_MAX: none): an
+                           // utterance with fewer frames is structurally infeasible
+    // ---- banded form (sweep_band_kernel): the non-final states in a topological order in which every
+    // emitting arc goes from position p - d to position p with 0 <= d <= BAND_BW
+    WF_I_BAND_BW = 40,     // band width, -1 when the graph has no such order (a cycle besides self-loops)
+    WF_I_BAND_M = 41,      // most arcs sharing one (p, d) cell
+    WF_I_BAND_ORDER = 42,  // [S-1] state at position p
+    WF_I_BANDF = 43,       // [S-1][BW+1][M] x {column, weight bits}: arcs INTO the state at p from p - d
+    WF_I_BANDB = 44,       // same for the backward sweep in reversed positions p' = S-2-p:
+                           // arcs OUT OF the state at p' to p' - d (reversed), i.e. to position p + d
 };
+// limits of the banded sweep (template instantiations in wf_kernels.hip)
+#define WF_BAND_MAX_BW 4
+#define WF_BAND_MAX_M 2
+#define WF_BAND_MAX_R 4
 
 // per-utterance table entry written by the host for each call (int64 words)
 enum {
@@ -74,6 +88,7 @@ enum {
     WF_U_S = 8, WF_U_A = 9, WF_U_K = 10, WF_U_DIRECT = 11, WF_U_MAXLABDEG = 12,
     WF_U_LAB_OFF = 13, WF_U_LAB_SRC = 14, WF_U_LAB_DST = 15, WF_U_LAB_COL = 16, WF_U_LAB_W = 17,
     WF_U_LABELS = 18,
-    WF_U_OFFS = 19,  // element offset of this utterance's per-frame offset rows (T+1 doubles)
+    WF_U_OFFS = 19,  // element offset of this utterance's per-group scale offsets (<= T+1 doubles)
+    WF_U_P = 20,     // element offset of the fp64 emission probabilities (linear-domain sweep)
     WF_U_WORDS = 24,
 };

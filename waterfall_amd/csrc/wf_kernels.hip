@@ -99,7 +99,11 @@ struct SweepArgs {
     double* totd;  // workspace copy of tot in fp64 for post_kernel (M_FB), may be null
     double* aoff;  // per-frame offsets of the renormalised fp32 alpha rows (register sweep, M_FB)
     double* boff;
-    double* tot2;  // tot in log2 units (quad sweep -> post kernels)
+    double* tot2;  // tot in log2 units (linear sweep -> check / post kernels)
+    const double* P;      // linear sweep: emission probabilities exp(lp - c_t), fp64, [utt](T x K)
+    const double* cmax;   // linear sweep: c_t per (utterance, frame) row, natural log units
+    double* ctot2;        // linear sweep: sum_t c_t in log2 units, per utterance
+    const int32_t* flag;  // fallback sweep: only utterances with flag[u] != 0 are processed
     int32_t* bp;   // viterbi back-pointers, arena int32: [utt](T x S)
     int32_t* fin_arc;  // viterbi: best final arc per utterance [B]
     int chunk;     // frames per emission chunk (ESTAGE)
@@ -230,6 +234,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
     constexpr int NDIR = (MODE == M_FB) ? 2 : 1;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int u = blockIdx.x / NDIR, dir = blockIdx.x % NDIR;
+    if (p.flag && !p.flag[u]) return;   // fallback pass: only the utterances the check flagged
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int fsa = (int)U[WF_U_FSA], T = (int)U[WF_U_T];
     const int32_t* blob = p.blob;
@@ -470,15 +475,16 @@ __device__ __forceinline__ int wave_min_i(int v) {
 
 template <int MODE, int R, int HD>
 __global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
+    static_assert(MODE != M_FB, "forward-only kernel: the forward-backward pass is sweep_lin_kernel / sweep_kernel");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool TROP = (MODE == M_TOT_MAX || MODE == M_VITERBI);
     constexpr bool LOGS = !TROP;
-    constexpr int NDIR = (MODE == M_FB) ? 2 : 1;
     constexpr int HDN = HD > 0 ? HD : 1;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const int slot = tid & 3, quad = tid >> 2, nq = nt >> 2;
-    const int u = blockIdx.x / NDIR, dir = blockIdx.x % NDIR;
+    const int u = blockIdx.x;
+    constexpr int dir = 0;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int fsa = (int)U[WF_U_FSA], T = (int)U[WF_U_T];
     const int32_t* blob = p.blob;
@@ -551,8 +557,6 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
     const int64_t estep = dir ? -epitch : epitch;
     const float* eload = ebase + (int64_t)(dir ? last_step : 0) * epitch;   // row of load index 0
 
-    float* arena = (float*)(dir ? p.beta : p.alpha) + U[dir ? WF_U_BETA : WF_U_ALPHA];
-    double* goff = (MODE == M_FB) ? (dir ? p.boff : p.aoff) + U[WF_U_OFFS] : nullptr;
     double coff = 0.0;   // current offset c (log2 units)
 
     {
@@ -562,12 +566,8 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
             if (dir) { const float f = fb[s]; v = (f == -INFINITY) ? -kBig : f * escale; }
             else v = (s == 0) ? 0.f : -kBig;
             cur[s] = v;
-            if (MODE == M_FB) arena[(int64_t)(dir ? T : 0) * S + s] = v;
         }
     }
-    // row written by step 0: forward alpha_1, backward beta_{T-1}; then +-S per step
-    float* srow = arena + (int64_t)(dir ? (T - 1) : 1) * S;
-    const int64_t sstep = dir ? -(int64_t)S : (int64_t)S;
     int32_t* bprow = (MODE == M_VITERBI) ? p.bp + U[WF_U_ALPHA] : nullptr;
 
     // ---- emission ring
@@ -619,7 +619,6 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
                 for (int j = 0; j < HDN; ++j) hx[j] -= m;
                 coff += (double)m;
             }
-            if (MODE == M_FB && tid == 0) goff[step / kPD] = coff;
         }
         float rowmax = -kBig;
         // ---- the high-degree state: one arc (or HD arcs) per lane, wave (DPP) + block (LDS) reduction
@@ -664,7 +663,6 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
             }
             if (tid == 0) {
                 nxt[over] = val;
-                if (MODE == M_FB) srow[over] = val;
                 if (MODE == M_VITERBI) bprow[over] = (val < kDead) ? -1 : barc;
                 rowmax = val;
             }
@@ -697,7 +695,6 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
             }
             if (writer[r]) {
                 nxt[sidx] = val;
-                if (MODE == M_FB) srow[sidx] = val;
                 if (MODE == M_VITERBI) bprow[sidx] = (val < kDead) ? -1 : barc;
             }
             if (LOGS) rowmax = fmaxf(rowmax, val);
@@ -706,7 +703,6 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
             const float wm = wave_max(rowmax);
             if (lane == 0) rmax[wave] = wm;
         }
-        srow += sstep;
         if (MODE == M_VITERBI) bprow += S;
         __syncthreads();
         float* t_ = cur; cur = nxt; nxt = t_;
@@ -773,13 +769,642 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_quad_kernel(SweepArgs p) {
                 for (int i = 1; i < nw; ++i) st += red[i];
                 const double tot2 = coff + (double)M + (double)__builtin_amdgcn_logf(st);
                 out = dead ? (double)-INFINITY : tot2 * kLn2;
-                if (MODE == M_FB && p.tot2) p.tot2[u] = dead ? (double)-INFINITY : tot2;
             }
             if (p.tot_double) ((double*)p.tot)[u] = out;
             else ((float*)p.tot)[u] = (float)out;
-            if (MODE == M_FB && p.totd) p.totd[u] = out;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Linear-domain forward-backward sweep: the fast path of wf_fb_logsum (loss + gradient).
+//
+// Measured on MI355X (tools/ubench/lat.hip): one frame step costs ~140 cycles for the LDS
+// read -> write -> barrier round trip alone, and every *dependent* VALU instruction adds 8-16 cycles
+// (4-cycle issue per wave64 instruction, times the waves sharing a SIMD).  A log-semiring step is a
+// chain of ~10 dependent operations including two transcendentals (add, max, max, sub, exp, add,
+// add, log, add); the same step in the probability domain is one multiply and three FMAs:
+//
+//      alpha^_{t+1}[d] = sum_a  alpha^_t[src(a)] * ( exp(w_a) * P_t[col(a)] ),   P_t[k] = exp(lp[t,k] - c_t)
+//
+// with everything except the FMA chain off the critical path (the products exp(w)*P for the next
+// frame are formed while the LDS reads of this frame are in flight).  fp64 carries the dynamic
+// range: c_t = max_k lp[t, label_k] takes out the per-frame scale (gather_lin_kernel) and every kLD
+// frames the row is multiplied by a power of two that steers its maximum to 2^800, so a state
+// underflows only when it is ~1800 bits (1250 nats) below the best state of its row.  That cannot
+// be told from a dead state inside the sweep, so check_kernel verifies afterwards that
+// sum_s alpha_t[s] * beta_t[s] = tot on every row; an utterance that fails (or totals to zero
+// without being structurally infeasible) is re-run by the log-semiring sweep_kernel (fallback).
+// Rows are stored as they are (scaled fp64) plus one cumulative shift per group of kLD frames; the
+// post kernels take log2 of them.  lane = state, arcs of the state (<= WF_REG_DEG) in VGPRs, at
+// most one high-degree state reduced by the whole workgroup, as in sweep_quad_kernel.
+// ------------------------------------------------------------------------------------------
+// emission ring depth = frames per rescale group: 8 where the register budget allows it (workgroups of
+// <= 256 lanes); every step waits for the vector-memory operations issued more than LD-1 steps
+// earlier (ring loads AND row stores share vmcnt), so LD steps must cover a store acknowledge
+// (600-950 cycles, MI355X_MICROARCH.md).
+constexpr int kLinBias = 800;          // the row maximum is steered to 2^kLinBias
+constexpr double kLog2eD = 1.4426950408889634074;
+
+__device__ __forceinline__ int f64_exp_field(double v) { return (__double2hiint(v) >> 20) & 0x7ff; }
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_d(double v) {   // lanes without a source receive 0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_d<0xB1, 0xf>(v);
+    v += dpp_d<0x4E, 0xf>(v);
+    v += dpp_d<0x114, 0xf>(v);
+    v += dpp_d<0x118, 0xf>(v);
+    v += dpp_d<0x142, 0xa>(v);
+    v += dpp_d<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    v = max(v, dpp_i<0xB1, 0xf>(v, v));
+    v = max(v, dpp_i<0x4E, 0xf>(v, v));
+    v = max(v, dpp_i<0x114, 0xf>(v, v));
+    v = max(v, dpp_i<0x118, 0xf>(v, v));
+    v = max(v, dpp_i<0x142, 0xa>(v, v));
+    v = max(v, dpp_i<0x143, 0xc>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// index of the cumulative shift carried by the row that sweep step s produced (s < 0: the initial row)
+// lag: steps between a rescale decision and the first row that carries it (sweep_lin_kernel 1, sweep_band_kernel 0)
+__device__ __forceinline__ int lin_shift_index(int s, int grp, int lag) { return s < lag ? 0 : (s - lag) / grp + 1; }
+
+// workgroup-uniform values that were read through vector loads: move them to SGPRs so that loop
+// counters and row pointers are advanced by the scalar unit
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni(int64_t v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffff));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((int64_t)hi << 32) | lo;
+}
+
+template <int HD, int NTMAX>
+__global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int D = WF_REG_DEG;
+    constexpr int kLD = NTMAX <= 256 ? 8 : 4;
+    constexpr int HDN = HD > 0 ? HD : 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int u = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int fsa = uni((int)U[WF_U_FSA]), T = uni((int)U[WF_U_T]);
+    const int32_t* blob = p.blob;
+    const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
+    const int S = uni(I[WF_I_S]), A = uni(I[WF_I_A]), K = uni(I[WF_I_K]);
+    if (T < uni(I[WF_I_MINLEN])) {   // structurally infeasible (models.py:305-313 mask_inf): no sweep needed
+        if (dir == 0 && tid == 0) {
+            ((float*)p.tot)[u] = -INFINITY;
+            p.totd[u] = (double)-INFINITY;
+            p.tot2[u] = (double)-INFINITY;
+            p.ctot2[u] = 0.0;
+        }
+        return;
+    }
+
+    double* cur = (double*)smem;
+    double* nxt = cur + p.smax;
+    double* red = nxt + p.smax;          // [16]
+    int* rexp = (int*)(red + 16);        // [16] per-wave maxima of the exponent field (unused waves: 0)
+
+    const int32_t* g_off = blob + uni(I[dir ? WF_I_OUT_OFF : WF_I_IN_OFF]);
+    const int32_t* g_oth = blob + uni(I[dir ? WF_I_OUT_DST : WF_I_IN_SRC]);
+    const int32_t* g_col = blob + uni(I[dir ? WF_I_OUT_COL : WF_I_IN_COL]);
+    const float* g_w = (const float*)(blob + uni(I[dir ? WF_I_OUT_W : WF_I_IN_W]));
+    const bool has_over = HD > 0 && uni(I[dir ? WF_I_NOVER_OUT : WF_I_NOVER_IN]) > 0;
+    const int over = has_over ? uni(I[dir ? WF_I_OVER_OUT : WF_I_OVER_IN]) : -1;
+    const bool mine = tid < S && tid != over;   // this lane owns state `tid`
+
+    // ---- this lane's arcs (padding: probability 0 from state 0, column 0)
+    int src[D], col[D];
+    double Wt[D];
+    {
+        int a0 = 0, deg = 0;
+        if (mine) { a0 = g_off[tid]; deg = g_off[tid + 1] - a0; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const bool valid = i < deg;
+            src[i] = valid ? g_oth[a0 + i] : 0;
+            col[i] = valid ? g_col[a0 + i] : 0;
+            Wt[i] = valid ? exp((double)g_w[a0 + i]) : 0.0;
+        }
+    }
+    int hsrc[HDN], hcol[HDN];
+    double hW[HDN];
+    {
+        int h0 = 0, h1 = 0;
+        if (has_over) { h0 = g_off[over]; h1 = g_off[over + 1]; }
+#pragma unroll
+        for (int j = 0; j < HDN; ++j) {
+            const int a = h0 + tid + j * nt;
+            const bool valid = HD > 0 && a < h1;
+            hsrc[j] = valid ? g_oth[a] : 0;
+            hcol[j] = valid ? g_col[a] : 0;
+            hW[j] = valid ? exp((double)g_w[a]) : 0.0;
+        }
+    }
+
+    // Loads are unconditional: load index n reads frame min(n, T-1) (time-reversed for beta); a graph
+    // without arcs or an empty segment reads the utterance table (small integers = finite tiny
+    // doubles) through a zero pitch.
+    const double* pbase = p.P + uni(U[WF_U_P]);
+    int64_t ppitch = K;
+    if (A == 0 || T == 0) { pbase = (const double*)U; ppitch = 0; }
+    const int last_step = max(T - 1, 0);
+    const int64_t pstep = dir ? -ppitch : ppitch;
+    const double* pload = pbase + (int64_t)(dir ? last_step : 0) * ppitch;   // row of load index 0
+
+    double* arena = (double*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
+    double* goff = (dir ? p.boff : p.aoff) + uni(U[WF_U_OFFS]);
+
+    // ---- initial vector (alpha_0 = delta(start); beta_T = final weights) and its exponent maximum
+    {
+        const float* fb = (const float*)(blob + uni(I[WF_I_FINB_LOG]));
+        int emax = 0;
+        for (int s = tid; s < S; s += nt) {
+            const double v = dir ? exp((double)fb[s]) : (s == 0 ? 1.0 : 0.0);
+            cur[s] = v;
+            arena[(int64_t)(dir ? T : 0) * S + s] = v;
+            emax = max(emax, f64_exp_field(v));
+        }
+        emax = wave_max_i(emax);
+        if (tid < 16) rexp[tid] = 0;
+        __syncthreads();
+        if (lane == 0) rexp[wave] = emax;
+        if (tid == 0) goff[0] = 0.0;
+    }
+    double* srow = arena + (int64_t)(dir ? (T - 1) : 1) * S;   // row written by step 0, then +-S per step
+    const int64_t sstep = dir ? -(int64_t)S : (int64_t)S;
+
+    // ---- emission ring: slot (step % kLD) holds the probabilities of frame step+1 while step runs
+    double pr[kLD][D], hpr[kLD][HDN];
+    double qc[D], qn[D], hqc[HDN], hqn[HDN];   // arc probabilities of this step / the next one
+#define WF_LOAD_ROW(DST, HDST)                                                      \
+    do {                                                                            \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) DST[i] = pload[col[i]];       \
+        if (HD > 0) {                                                               \
+            _Pragma("unroll") for (int j = 0; j < HDN; ++j) HDST[j] = pload[hcol[j]]; \
+        }                                                                           \
+    } while (0)
+    WF_LOAD_ROW(qc, hqc);   // load index 0 = frame 0
+    if (0 < last_step) pload += pstep;
+#pragma unroll
+    for (int k = 0; k < kLD; ++k) {   // load indices 1 .. kLD
+        WF_LOAD_ROW(pr[k], hpr[k]);
+        if (k + 1 < last_step) pload += pstep;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) qc[i] *= Wt[i];
+#pragma unroll
+    for (int j = 0; j < HDN; ++j) hqc[j] *= hW[j];
+    double cum = 0.0, cum_last = 0.0;   // cumulative power-of-two shift (log2 units) carried by the rows
+    __syncthreads();
+
+    auto do_step = [&](const int step, const int k) __attribute__((always_inline)) {
+        // ---- critical path, part 1: issue the LDS reads of the source states' alpha
+        double a[D], ha[HDN];
+#pragma unroll
+        for (int i = 0; i < D; ++i) a[i] = cur[src[i]];
+#pragma unroll
+        for (int j = 0; j < HDN; ++j) ha[j] = (HD > 0) ? cur[hsrc[j]] : 0.0;
+        int4 rx[4];
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rx[i] = ((const int4*)rexp)[i];
+        }
+        // ---- in the shadow of the LDS latency: next step's arc probabilities from ring slot k, which
+        // is then refilled (load index step+1+kLD).  The values are pinned before the refill so that it
+        // lands in the same registers (otherwise hipcc rotates the ring with copies behind a vmcnt(0)).
+#pragma unroll
+        for (int i = 0; i < D; ++i) { qn[i] = Wt[i] * pr[k][i]; asm volatile("" : "+v"(qn[i])); }
+#pragma unroll
+        for (int j = 0; j < HDN; ++j) { hqn[j] = hW[j] * hpr[k][j]; asm volatile("" : "+v"(hqn[j])); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.ablate & 2)) WF_LOAD_ROW(pr[k], hpr[k]);
+        if (step + 1 + kLD < last_step) pload += pstep;
+        cum_last = cum;
+        if (k == 0 && !(p.ablate & 4)) {
+            // rescale decision from the row finished at the end of the previous group
+            int4 m4 = rx[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) { m4.x = max(m4.x, rx[i].x); m4.y = max(m4.y, rx[i].y); m4.z = max(m4.z, rx[i].z); m4.w = max(m4.w, rx[i].w); }
+            const int emax = max(max(m4.x, m4.y), max(m4.z, m4.w));
+            const int sh = emax > 0 ? (1023 + kLinBias) - emax : 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) qn[i] = ldexp(qn[i], sh);
+#pragma unroll
+            for (int j = 0; j < HDN; ++j) hqn[j] = ldexp(hqn[j], sh);
+            cum += (double)sh;
+            if (tid == 0) goff[step / kLD + 1] = cum;
+        }
+        // ---- critical path, part 2
+        int emine = 0;
+        if (HD > 0 && has_over) {
+            double part = 0.0;
+#pragma unroll
+            for (int j = 0; j < HDN; ++j) part = fma(ha[j], hqc[j], part);
+            double tot_h = wave_sum_d(part);
+            if (nw > 1) {
+                if (lane == 0) red[wave] = tot_h;
+                __syncthreads();
+                if (tid == 0) {
+                    tot_h = red[0];
+                    for (int i = 1; i < nw; ++i) tot_h += red[i];
+                }
+            }
+            if (tid == 0) {
+                nxt[over] = tot_h;
+                srow[over] = tot_h;
+                emine = f64_exp_field(tot_h);
+            }
+        }
+        double v = a[0] * qc[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) v = fma(a[i], qc[i], v);
+        if (mine) {
+            nxt[tid] = v;
+            if (!(p.ablate & 1)) srow[tid] = v;
+            emine = max(emine, f64_exp_field(v));
+        }
+        if (k == kLD - 1 && !(p.ablate & 4)) {
+            const int em = wave_max_i(emine);
+            if (lane == 0) rexp[wave] = em;
+        }
+        srow += sstep;
+#pragma unroll
+        for (int i = 0; i < D; ++i) qc[i] = qn[i];
+#pragma unroll
+        for (int j = 0; j < HDN; ++j) hqc[j] = hqn[j];
+        __syncthreads();
+        double* t_ = cur; cur = nxt; nxt = t_;
+    };
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+    int t0 = 0;
+    for (; t0 + kLD <= T; t0 += kLD) {
+#pragma unroll
+        for (int k = 0; k < kLD; ++k) do_step(t0 + k, k);
+    }
+#pragma unroll
+    for (int k = 0; k < kLD; ++k)
+        if (t0 + k < T) do_step(t0 + k, k);
+#undef WF_LOAD_ROW
+    if ((p.ablate & 8) && blockIdx.x == 0 && tid == 0)
+        printf("sweep_lin: T=%d nt=%d cycles/step=%.1f\n", T, nt, (double)(__builtin_amdgcn_s_memtime() - clk0) / max(T, 1));
+
+    // ---- forward workgroup: total score = log(sum over final arcs) - shifts + sum_t c_t
+    if (dir == 0) {
+        const int NF = I[WF_I_NF];
+        const int32_t* fsrc = blob + I[WF_I_FIN_SRC];
+        const float* fw = (const float*)(blob + I[WF_I_FIN_W]);
+        double part = 0.0, csum = 0.0;
+        for (int i = tid; i < NF; i += nt) part = fma(cur[fsrc[i]], exp((double)fw[i]), part);
+        const double* crow = p.cmax + U[WF_U_ROW0];
+        for (int t = tid; t < T; t += nt) csum += crow[t];
+        part = wave_sum_d(part);
+        csum = wave_sum_d(csum);
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        // two rounds through the 16 reduction slots: final-arc sums, then the c_t sums
+        double fsum = 0.0;
+        if (tid == 0) for (int i = 0; i < nw; ++i) fsum += red[i];
+        __syncthreads();
+        if (lane == 0) red[wave] = csum;
+        __syncthreads();
+        if (tid == 0) {
+            double ct = 0.0;
+            for (int i = 0; i < nw; ++i) ct += red[i];
+            const double ctot2 = ct * kLog2eD;
+            const bool dead = !(fsum > 0.0);
+            const double tot2 = dead ? (double)-INFINITY : log2(fsum) - cum_last + ctot2;
+            const double tot = dead ? (double)-INFINITY : tot2 * kLn2;
+            p.tot2[u] = tot2;
+            p.ctot2[u] = ctot2;
+            p.totd[u] = tot;
+            ((float*)p.tot)[u] = (float)tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Banded wave sweep: the linear-domain forward-backward recursion of a numerator graph with NO LDS
+// round trip and NO barrier on the critical path.
+//
+// Every topo o transcript graph has a topological order of its states in which each arc goes from
+// position p - d to position p with 0 <= d <= BW <= 4 (wf_graph.cpp, WF_I_BAND_*).  ONE wavefront (the
+// chain wave) then carries the whole state vector in registers, R consecutive positions per lane:
+// the sources of a state are in the same lane or in lane - 1, fetched with a wave_shr:1 DPP move, and
+// a frame step is BW DPP moves + R*(BW+1) fp64 FMAs, about 70-100 cycles instead of the ~440 of the
+// LDS/barrier recursion (measured, tools/ubench/band.hip).  Everything else runs beside it on the
+// other three SIMDs of the CU (helper waves): the arc probabilities q[p][d] = sum_m exp(w_m) *
+// P_t[col_m] of the NEXT chunk of C frames go into an LDS double buffer (emissions prefetched one
+// more chunk ahead in registers), and the alpha rows of the PREVIOUS chunk go from an LDS double
+// buffer to the workspace.  Chain and helpers meet at one barrier per chunk.  The backward sweep is
+// the same code on the reversed order.  Rescaling (chain wave, once per chunk) and the row check /
+// fallback are as for sweep_lin_kernel.
+// ------------------------------------------------------------------------------------------
+template <int R, int BW>
+struct BandCfg {
+    static constexpr int NQ = R * (BW + 1);            // coefficients per lane per frame
+    static constexpr int NQP = (NQ + 1) / 2;           // ... read as 16-byte pairs
+    static constexpr int NH = (NQ % 3 == 0) ? 3 : 4;   // helper waves (NQ must split evenly over them)
+    static constexpr int OWN = NQ / NH;                // (coefficient, lane) cells a helper lane owns
+    static constexpr int C = (NQ <= 12) ? 8 : 4;       // frames per chunk
+    static constexpr int NT = 64 * (1 + NH);
+    static constexpr size_t QBYTES = (size_t)C * NQP * 64 * 16;   // one chunk of coefficients
+    static constexpr size_t LDS = 2 * QBYTES + 2 * 64 * 4 + 16;   // + per-lane exponents (x2) + shift words
+    static_assert(NQ % NH == 0, "coefficients must split evenly over the helper waves");
+    static_assert(BW <= R, "sources must sit in the same lane or the previous one");
+};
+
+// MM: arcs per (position, distance) cell the instantiation handles (1: deterministic topologies)
+template <int R, int BW, int MM>
+__global__ void __launch_bounds__(64 * (1 + ((R * (BW + 1)) % 3 == 0 ? 3 : 4))) sweep_band_kernel(SweepArgs p) {
+    using Cfg = BandCfg<R, BW>;
+    constexpr int NQ = Cfg::NQ, NQP = Cfg::NQP, NH = Cfg::NH, OWN = Cfg::OWN, C = Cfg::C;
+    static_assert(MM >= 1 && MM <= WF_BAND_MAX_M, "cell capacity");
+    extern __shared__ __align__(16) unsigned char smem[];
+    // LDS: coefficient double buffer [2][C][NQP][64] x 16 B, then 2 x 64 exponent words, then 2 shift words
+    int* ebuf = (int*)(smem + 2 * Cfg::QBYTES);
+    int* shw = ebuf + 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int fsa = uni((int)U[WF_U_FSA]), T = uni((int)U[WF_U_T]);
+    const int32_t* blob = p.blob;
+    const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
+    const int S = uni(I[WF_I_S]), A = uni(I[WF_I_A]), K = uni(I[WF_I_K]);
+    if (T < uni(I[WF_I_MINLEN])) {   // structurally infeasible: no sweep needed
+        if (dir == 0 && tid == 0) {
+            ((float*)p.tot)[u] = -INFINITY;
+            p.totd[u] = (double)-INFINITY;
+            p.tot2[u] = (double)-INFINITY;
+            p.ctot2[u] = 0.0;
+        }
+        return;
+    }
+    const int Sn = S - 1;   // positions: every state but the super-final one
+    const int gbw = uni(I[WF_I_BAND_BW]), gm = uni(I[WF_I_BAND_M]);
+    const int32_t* order = blob + uni(I[WF_I_BAND_ORDER]);
+    const int32_t* tab = blob + uni(I[dir ? WF_I_BANDB : WF_I_BANDF]);
+    const float* fb = (const float*)(blob + uni(I[WF_I_FINB_LOG]));
+    const int nc = (T + C - 1) / C;
+    double* arena = (double*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
+    double* goff = (dir ? p.boff : p.aoff) + uni(U[WF_U_OFFS]);
+    if (tid < 2) shw[tid] = tid == 0 ? kLinBias : 0;   // chunk 0: the initial vector's maximum is 1; chunk 1: nothing measured yet
+
+    if (wave == 0) {
+        // =============================== chain wave ===============================
+        double a[R];
+        unsigned soff[R];   // byte offset of the state inside an alpha row; padding positions write the
+                            // (unused) super-final column, so that no store needs an exec mask
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int pp = lane * R + r;
+            int st = -1;
+            if (pp < Sn) st = order[dir ? Sn - 1 - pp : pp];
+            a[r] = st < 0 ? 0.0 : (dir ? exp((double)fb[st]) : (st == 0 ? 1.0 : 0.0));
+            soff[r] = (unsigned)(st < 0 ? S - 1 : st) * 8u;
+            *(double*)((char*)(arena + (int64_t)(dir ? T : 0) * S) + soff[r]) = a[r];   // alpha_0 / beta_T
+        }
+        if (lane == 0) goff[0] = 0.0;
+        double cum = 0.0;   // cumulative power-of-two shift (log2 units) carried by the rows
+        // row written by step 0: alpha_1 / beta_{T-1}; then +-S doubles per step
+        char* srow = (char*)(arena + (int64_t)(dir ? (T - 1) : 1) * S);
+        const int64_t sstep = (dir ? -(int64_t)S : (int64_t)S) * 8;
+        const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        auto load_q = [&](const char* qb, const int k, d2 (&q)[NQP]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NQP; ++j) q[j] = *(const d2*)(qb + (size_t)(k * NQP + j) * 1024);
+        };
+        auto step = [&](const d2 (&q)[NQP]) __attribute__((always_inline)) {
+            double nb[BW];   // nb[j]: the state at position lane*R - 1 - j (slot R-1-j of lane - 1)
+#pragma unroll
+            for (int j = 0; j < BW; ++j) nb[j] = dpp_d<0x138, 0xf>(a[R - 1 - j]);   // wave_shr:1, lane 0 receives 0
+            double an[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double v = 0.0;
+#pragma unroll
+                for (int d = 0; d <= BW; ++d) {
+                    const int jq = r * (BW + 1) + d;
+                    const double qq = (jq & 1) ? q[jq >> 1].y : q[jq >> 1].x;
+                    const double sv = (r - d >= 0) ? a[r - d >= 0 ? r - d : 0] : nb[d - r - 1 >= 0 ? d - r - 1 : 0];
+                    v = (d == 0) ? sv * qq : fma(sv, qq, v);
+                }
+                an[r] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                a[r] = an[r];
+                if (!(p.ablate & 4)) *(double*)(srow + soff[r]) = an[r];
+            }
+            srow += sstep;
+        };
+        for (int c = 0; c < nc; ++c) {
+            __syncthreads();   // the coefficients of chunk c are in place
+            const char* qb = (const char*)smem + (size_t)(c & 1) * Cfg::QBYTES + lane * 16;
+            d2 q0[NQP], q1[NQP];
+            load_q(qb, 0, q0);
+            {   // rescale by the power of two the helpers derived from the row two chunks back
+                const int sh = uni(shw[c & 1]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) a[r] = ldexp(a[r], sh);
+                cum += (double)sh;
+                if (lane == 0) goff[c + 1] = cum;
+            }
+            const int nk = min(C, T - c * C);
+            if (nk == C) {   // full chunk: no per-step test; the next step's coefficients are read a step ahead
+#pragma unroll
+                for (int k = 0; k < C; k += 2) {
+                    load_q(qb, k + 1, q1);
+                    step(q0);
+                    if (k + 2 < C) load_q(qb, k + 2, q0);
+                    step(q1);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    if (k < nk) {
+                        if (k > 0) load_q(qb, k, q0);
+                        step(q0);
+                    }
+                }
+            }
+            {   // this lane's largest exponent, for the helpers' next rescale decision
+                int e = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) e = max(e, f64_exp_field(a[r]));
+                ebuf[(c & 1) * 64 + lane] = e;
+            }
+        }
+        __syncthreads();
+        if ((p.ablate & 8) && blockIdx.x == 0 && lane == 0)
+            printf("sweep_band<%d,%d,%d>: T=%d cycles/step=%.1f\n", R, BW, MM, T, (double)(__builtin_amdgcn_s_memtime() - clk0) / max(T, 1));
+        if (dir == 0) {
+            // total = sum over positions of alpha_T * exp(final weight), then undo the scaling
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int pp = lane * R + r;
+                if (pp < Sn) part = fma(a[r], exp((double)fb[order[pp]]), part);
+            }
+            double csum = 0.0;
+            const double* crow = p.cmax + uni(U[WF_U_ROW0]);
+            for (int t = lane; t < T; t += 64) csum += crow[t];
+            const double fsum = wave_sum_d(part);
+            const double ctot2 = wave_sum_d(csum) * kLog2eD;
+            if (lane == 0) {
+                const bool dead = !(fsum > 0.0);
+                const double tot2 = dead ? (double)-INFINITY : log2(fsum) - cum + ctot2;
+                const double tot = dead ? (double)-INFINITY : tot2 * kLn2;
+                p.tot2[u] = tot2;
+                p.ctot2[u] = ctot2;
+                p.totd[u] = tot;
+                ((float*)p.tot)[u] = (float)tot;
+            }
+        }
+    } else {
+        // =============================== helper waves ===============================
+        const int h = tid - 64;
+        // the (coefficient, lane) cells this lane produces: cell e = h + i*NH*64 -> coefficient e / 64 of lane e % 64
+        unsigned coff[OWN][MM];   // byte offset of the arc's column inside a P row
+        double cw[OWN][MM];       // exp(arc weight); 0 for an empty cell
+        unsigned qoff[OWN];       // byte offset of the cell inside one frame's coefficient block
+#pragma unroll
+        for (int i = 0; i < OWN; ++i) {
+            const int e = h + i * NH * 64;
+            const int j = e >> 6, ln = e & 63;
+            const int r = j / (BW + 1), d = j % (BW + 1);
+            const int pp = ln * R + r;
+            const bool cell = pp < Sn && d <= gbw;
+            qoff[i] = (unsigned)(((j >> 1) * 64 + ln) * 16 + (j & 1) * 8);
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                int col = 0;
+                float w = -INFINITY;
+                if (cell && m < gm) {
+                    const int32_t* ent = tab + (((size_t)pp * (gbw + 1) + d) * gm + m) * 2;
+                    col = ent[0];
+                    w = __int_as_float(ent[1]);
+                }
+                coff[i][m] = (unsigned)col * 8u;
+                cw[i][m] = exp((double)w);
+            }
+        }
+        const char* pbase = (const char*)(p.P + uni(U[WF_U_P]));
+        int64_t ppitch = (int64_t)K * 8;
+        if (A == 0 || T == 0) { pbase = (const char*)U; ppitch = 0; }   // finite dummies (the utterance table)
+        const int last_step = max(T - 1, 0);
+        double pre[C][OWN][MM];
+        auto issue = [&](const int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const int s = min(c * C + k, last_step);
+                const char* row = pbase + (int64_t)(dir ? T - 1 - s : s) * ppitch;
+#pragma unroll
+                for (int i = 0; i < OWN; ++i)
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) pre[k][i][m] = *(const double*)(row + coff[i][m]);
+            }
+        };
+        auto produce = [&](const int c) __attribute__((always_inline)) {
+            char* qb = (char*)smem + (size_t)(c & 1) * Cfg::QBYTES;
+#pragma unroll
+            for (int k = 0; k < C; ++k)
+#pragma unroll
+                for (int i = 0; i < OWN; ++i) {
+                    double q = cw[i][0] * pre[k][i][0];
+#pragma unroll
+                    for (int m = 1; m < MM; ++m) q = fma(cw[i][m], pre[k][i][m], q);
+                    *(double*)(qb + (size_t)k * NQP * 1024 + qoff[i]) = q;
+                }
+        };
+        if (nc > 0) {
+            issue(0);
+            produce(0);
+            if (nc > 1) issue(1);
+        }
+        for (int c = 0; c <= nc; ++c) {
+            __syncthreads();
+            if (c + 1 < nc && !(p.ablate & 2)) {
+                produce(c + 1);
+                if (c + 2 < nc) issue(c + 2);
+            }
+            if (wave == 1 && c >= 1) {
+                // ebuf holds the exponents at the end of chunk c-1, before the shift shw[c&1] that chunk c
+                // applies: decide the shift of chunk c+1 so that the maximum returns to 2^kLinBias
+                const int e = wave_max_i(ebuf[((c - 1) & 1) * 64 + lane]);
+                const int sh_c = uni(shw[c & 1]);
+                const int sh = e > 0 ? (1023 + kLinBias) - (e + sh_c) : 0;
+                if (lane == 0) shw[(c + 1) & 1] = sh;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// check_kernel: one wavefront per (utterance, row t in 0..T).  Every path crosses exactly one state
+// at time t, so sum_s alpha_t[s] * beta_t[s] = tot on every row; a row of the linear sweep that lost
+// mass to underflow (or overflowed) breaks the identity.  Sets flag[u] for the fallback sweep.
+// ------------------------------------------------------------------------------------------
+constexpr float kCheckTol = 1e-4f;
+
+struct CheckArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const double* alpha;
+    const double* beta;
+    const double* aoff;
+    const double* boff;
+    const double* tot2;
+    const double* ctot2;
+    int32_t* flag;
+    int grp, lag;   // frames per rescale group of the sweep that wrote the rows; see lin_shift_index
+};
+
+// log2 of a non-negative double as (integer part exactly, fraction in fp32): log2(0) = -inf
+__device__ __forceinline__ void log2_split(double v, double& e, float& f) {
+    e = (double)__builtin_amdgcn_frexp_exp(v);
+    f = __builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(v));
+}
+
+__global__ void __launch_bounds__(64) check_kernel(CheckArgs p) {
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x, u = blockIdx.y;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int T = (int)U[WF_U_T];
+    if (t > T) return;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int S = (int)U[WF_U_S];
+    const double tot2 = p.tot2[u];
+    if (tot2 == (double)-INFINITY) {
+        // zero total: fine when no path of this length exists, otherwise the sweep underflowed
+        if (t == 0 && lane == 0 && T >= I[WF_I_MINLEN]) p.flag[u] = 1;
+        return;
+    }
+    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)t * S;
+    // alpha row t came from forward step t-1, beta row t from backward step T-1-t
+    const double cst = p.ctot2[u] - tot2 - p.aoff[U[WF_U_OFFS] + lin_shift_index(t - 1, p.grp, p.lag)] -
+                       p.boff[U[WF_U_OFFS] + lin_shift_index(T - 1 - t, p.grp, p.lag)];
+    float sum = 0.f;
+    for (int s = lane; s < S - 1; s += 64) {   // the super-final state carries no mass at t <= T
+        double ea, eb;
+        float fa, fb;
+        log2_split(arow[s], ea, fa);
+        log2_split(brow[s], eb, fb);
+        sum += __builtin_amdgcn_exp2f((float)(ea + eb + cst) + (fa + fb));   // exp2(-inf) = 0 for dead states
+    }
+    sum = wave_sum(sum);
+    if (lane == 0 && !(fabsf(sum - 1.f) <= kCheckTol)) p.flag[u] = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -811,6 +1436,62 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherArgs p) {
     }
 }
 
+// Emission stage of the linear sweep: one wavefront per (frame, utterance).
+//   c_t = max_k lp[t, label_k]      P[t,k] = exp(lp[t, label_k] - c_t)  (fp64: range, not precision)
+// Compact graphs also keep the raw gathered values E[t,k] (read by the post kernels and by the
+// fallback sweep).  Also clears the utterance's fallback flag.
+constexpr int kGV = 8;   // values a lane keeps in registers between the two passes over the row
+
+struct GatherLinArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const float* lp;
+    int64_t strideB, strideT;
+    float* E;
+    double* P;
+    double* cmax;
+    int32_t* flag;
+};
+
+__global__ void __launch_bounds__(64) gather_lin_kernel(GatherLinArgs p) {
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x, u = blockIdx.y;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    if (t == 0 && lane == 0) p.flag[u] = 0;
+    const int T = (int)U[WF_U_T];
+    if (t >= T) return;
+    const int K = (int)U[WF_U_K], direct = (int)U[WF_U_DIRECT];
+    const int32_t* labels = p.blob + U[WF_U_LABELS];
+    const float* row = p.lp + U[WF_U_SEQ] * p.strideB + (U[WF_U_START] + t) * p.strideT;
+    float v[kGV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kGV; ++i) {
+        const int k = lane + 64 * i;
+        v[i] = (k < K) ? row[direct ? k : labels[k]] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+    for (int k = lane + 64 * kGV; k < K; k += 64) m = fmaxf(m, row[direct ? k : labels[k]]);
+    m = wave_max(m);
+    if (!(m > -INFINITY)) m = 0.f;   // every label impossible in this frame: P = 0
+    double* prow = p.P + U[WF_U_P] + (int64_t)t * K;
+    float* erow = p.E + U[WF_U_E] + (int64_t)t * K;
+#pragma unroll
+    for (int i = 0; i < kGV; ++i) {
+        const int k = lane + 64 * i;
+        if (k < K) {
+            prow[k] = exp((double)v[i] - (double)m);
+            if (!direct) erow[k] = v[i];
+        }
+    }
+    for (int k = lane + 64 * kGV; k < K; k += 64) {
+        const float x = row[direct ? k : labels[k]];
+        prow[k] = exp((double)x - (double)m);
+        if (!direct) erow[k] = x;
+    }
+    if (lane == 0) p.cmax[U[WF_U_ROW0] + t] = (double)m;
+}
+
 // ------------------------------------------------------------------------------------------
 // posterior / gradient rows
 // ------------------------------------------------------------------------------------------
@@ -825,25 +1506,36 @@ struct PostArgs {
     const double* alpha;
     const double* beta;
     const double* totd;
-    const double* tot2;   // tot in log2 units (quad sweep), valid when ab_float
+    const double* tot2;   // linear sweep: tot in log2 units
+    const double* ctot2;  // linear sweep: sum_t c_t in log2 units
+    const double* cmax;   // linear sweep: c_t per row (natural units)
+    const int32_t* flag;  // linear sweep: utterances re-run by the fallback (their rows are log-domain fp64)
     float* grad;
     int Tmax, V, smax;
     int ecap;       // LDS floats reserved for the staged emission row (compact graphs), 0 = none
     int acap;       // LDS floats reserved for per-arc posteriors (arc-parallel mode), 0 = column loop
     int skip_zero;  // rows were zero-filled by zero_kernel already: only scatter the K values
     int fr;         // frames per workgroup
-    int ab_float;   // alpha/beta rows are renormalised fp32 (log2 units) + per-group fp64 offsets (quad sweep)
+    int lin;        // != 0: the call used sweep_lin_kernel (rows are scaled probabilities, fp64, + per-group
+                    // shifts); the value is the sweep's frames per rescale group
+    int lag;        // see lin_shift_index
     const double* aoff;
     const double* boff;
 };
 
-// Quad-sweep rows are stored relative to a per-group offset: alpha row t (t >= 1) was produced by
-// forward step t-1, beta row t+1 (< T) by backward step T-2-t; rows 0 / T are the unscaled initial
-// vectors.  Returns off_a(t) + off_b(t+1) in log2 units.
-__device__ __forceinline__ double ab_offsets(const double* aoffs, const double* boffs, int t, int T) {
-    const double ga = t > 0 ? aoffs[(t - 1) / kPD] : 0.0;
-    const double gb = (t + 1 < T) ? boffs[(T - 2 - t) / kPD] : 0.0;
-    return ga + gb;
+// log2(v) + add for a scaled probability of the linear sweep (0 -> -inf)
+__device__ __forceinline__ float lin_log2f(double v, double add) {
+    double e;
+    float f;
+    log2_split(v, e, f);
+    return (float)(e + add) + f;
+}
+// Linear-sweep rows: alpha row t came from forward step t-1, beta row t+1 from backward step T-2-t.
+// Returns the constant that turns log2(alpha^) + log2(beta^) + log2e*(w + e) into the log2 posterior
+// of an arc in frame t:  sum of the other frames' c - shifts - tot.
+__device__ __forceinline__ double lin_post_const(const PostArgs& p, const int64_t* U, int u, int t, int T) {
+    return p.ctot2[u] - p.cmax[U[WF_U_ROW0] + t] * kLog2eD - p.tot2[u] -
+           p.aoff[U[WF_U_OFFS] + lin_shift_index(t - 1, p.lin, p.lag)] - p.boff[U[WF_U_OFFS] + lin_shift_index(T - 2 - t, p.lin, p.lag)];
 }
 
 // zero n floats starting at p (4-byte aligned) with 16-byte stores where alignment allows
@@ -913,15 +1605,12 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     const int S = I[WF_I_S], A = I[WF_I_A], K = I[WF_I_K], direct = I[WF_I_DIRECT];
     const double* abase = p.alpha + U[WF_U_ALPHA];
     const double* bbase = p.beta + U[WF_U_BETA];
-    const float* abase_f = (const float*)p.alpha + U[WF_U_ALPHA];
-    const float* bbase_f = (const float*)p.beta + U[WF_U_BETA];
-    const bool abf = p.ab_float != 0;
-    // posterior = exp2(xs * (alpha + beta) + es * (w + e)): quad-sweep rows are already in log2 units
-    const float xs = abf ? 1.f : kLog2e, es = kLog2e;
-    const double* aoffs = p.aoff + U[WF_U_OFFS];
-    const double* boffs = p.boff + U[WF_U_OFFS];
-    auto ldA = [&](int64_t i) { return abf ? (double)abase_f[i] : abase[i]; };
-    auto ldB = [&](int64_t i) { return abf ? (double)bbase_f[i] : bbase[i]; };
+    // row format: scaled probabilities (linear sweep) or natural-log scores (log-semiring sweep / fallback)
+    const bool lin = p.lin && !p.flag[u];
+    // posterior = exp2(xs * (la + lb) + es * (w + e)): la / lb of linear-sweep rows are already log2
+    const float xs = lin ? 1.f : kLog2e, es = kLog2e;
+    auto ldA = [&](int64_t i) { return abase[i]; };
+    auto ldB = [&](int64_t i) { return bbase[i]; };
     const float* ebase = direct ? p.lp + (int64_t)q * p.strideB + (int64_t)start * p.strideT : p.E + U[WF_U_E];
     const int64_t epitch = direct ? p.strideT : K;
     const bool stage_e = !direct && K <= p.ecap;
@@ -962,7 +1651,7 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
             if (stage_e && tid < K) le[tid] = pe;
             prefetch(t + 1 < T && f + 1 < f1 ? t + 1 : -1);
         } else {
-            if (!abf)
+            if (!lin)
                 for (int s = tid; s < S; s += nt) mx = fmax(mx, ldA(arow + s));
             if (stage_e)
                 for (int k = tid; k < K; k += nt) le[k] = erow[k];
@@ -978,16 +1667,18 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
         double a_ref = wmax[0];
         for (int x = 1; x < nwv; ++x) a_ref = fmax(a_ref, wmax[x]);
         double b_ref = tot - a_ref;
-        if (abf) {   // rows are already relative to their offsets: fold (off_a + off_b - tot) into alpha
-            a_ref = -(ab_offsets(aoffs, boffs, t, T) - p.tot2[u]);
-            b_ref = 0.0;
+        if (lin) {   // log2 of the scaled probabilities, both centred on the rescale target
+            a_ref = lin_post_const(p, U, u, t, T) + (double)kLinBias;
+            b_ref = -(double)kLinBias;
         }
+        auto cvA = [&](double v) { return lin ? lin_log2f(v, a_ref) : (float)(v - a_ref); };
+        auto cvB = [&](double v) { return lin ? lin_log2f(v, b_ref) : (float)(v - b_ref); };
         if (SMALL) {
-            if (tid < S) { la[tid] = (float)(ca - a_ref); lb[tid] = (float)(cb - b_ref); }
+            if (tid < S) { la[tid] = cvA(ca); lb[tid] = cvB(cb); }
         } else {
             for (int s = tid; s < S; s += nt) {
-                la[s] = (float)(ldA(arow + s) - a_ref);
-                lb[s] = (float)(ldB(brow + s) - b_ref);
+                la[s] = cvA(ldA(arow + s));
+                lb[s] = cvB(ldB(brow + s));
             }
         }
         __syncthreads();
@@ -1044,10 +1735,10 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     const double tot = p.totd[u];
     if (t < 0 || t >= T || tot == (double)-INFINITY) return;
     const int S = (int)U[WF_U_S], A = (int)U[WF_U_A], K = (int)U[WF_U_K];
-    const float* arow = (const float*)p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
-    const float* brow = (const float*)p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
     const float* erow = p.E + U[WF_U_E] + (int64_t)t * K;
-    const float cst = (float)(ab_offsets(p.aoff + U[WF_U_OFFS], p.boff + U[WF_U_OFFS], t, T) - p.tot2[u]);
+    const bool lin = !p.flag[u];   // flagged: the fallback left natural-log fp64 rows
     const int32_t* loff = p.blob + U[WF_U_LAB_OFF];
     const int32_t* lsrc = p.blob + U[WF_U_LAB_SRC];
     const int32_t* ldst = p.blob + U[WF_U_LAB_DST];
@@ -1058,11 +1749,10 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
 
     // ---- batch 2: all independent loads (indices clamped so that no load is conditional)
-    float av[kPS], bv[kPS];
+    double av[kPS], bv[kPS];
     float ev[kPS];
     int asrc[kPS], adst[kPS], acol[kPS];
     float aw[kPS];
-    int k0[2], k1[2], klab[2];
 #pragma unroll
     for (int i = 0; i < kPS; ++i) {
         const int s = min(lane + i * 64, S - 1);
@@ -1072,17 +1762,36 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
         const int a = min(lane + i * 64, A - 1);
         asrc[i] = lsrc[a]; adst[i] = ldst[a]; acol[i] = lcol[a]; aw[i] = lw[a];
     }
+    double a_ref, b_ref;
+    float xs;
+    if (lin) {
+        a_ref = lin_post_const(p, U, u, t, T) + (double)kLinBias;
+        b_ref = -(double)kLinBias;
+        xs = 1.f;
+    } else {
+        double mx = (double)-INFINITY;
+#pragma unroll
+        for (int i = 0; i < kPS; ++i) mx = fmax(mx, av[i]);   // clamped duplicates do not change the maximum
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, shfl_xor(mx, o));
+        a_ref = mx;
+        b_ref = tot - mx;
+        xs = kLog2e;
+    }
 #pragma unroll
     for (int i = 0; i < kPS; ++i) {
         const int s = lane + i * 64;
-        if (s < S) { la[s] = av[i] + cst; lb[s] = bv[i]; }
+        if (s < S) {
+            la[s] = lin ? lin_log2f(av[i], a_ref) : (float)(av[i] - a_ref);
+            lb[s] = lin ? lin_log2f(bv[i], b_ref) : (float)(bv[i] - b_ref);
+        }
         if (s < K) le[s] = ev[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kPS; ++i) {
         const int a = lane + i * 64;
-        if (a < A) lpost[a] = __builtin_amdgcn_exp2f(la[asrc[i]] + (aw[i] + le[acol[i]]) * kLog2e + lb[adst[i]]);
+        if (a < A) lpost[a] = __builtin_amdgcn_exp2f((la[asrc[i]] + lb[adst[i]]) * xs + (aw[i] + le[acol[i]]) * kLog2e);
     }
     __syncthreads();
     // per-column sums in arc order (bit-stable)
@@ -1136,15 +1845,17 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
     int B = 0;
-    size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_totd = 0, off_tot2 = 0, off_aoff = 0, off_boff = 0, off_E = 0, off_alpha = 0, off_beta = 0,
-           off_bp = 0, off_finarc = 0, total = 0;
+    size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_totd = 0, off_tot2 = 0, off_ctot2 = 0, off_flag = 0, off_aoff = 0,
+           off_boff = 0, off_E = 0, off_P = 0, off_cmax = 0, off_alpha = 0, off_beta = 0, off_bp = 0, off_finarc = 0, total = 0;
     std::vector<int64_t> utt;  // B * WF_U_WORDS
     int smax = 0, kmax_compact = 0, kmax = 0, amax = 0, hmax = 0, maxlabdeg = 0;
     bool any_compact = false, all_compact = true, any_heavy = false, arcs_lds_ok = true;
     // register-resident sweep eligibility (per direction)
     bool reg_ok_in = true, reg_ok_out = true;
     int over_deg_in = 0, over_deg_out = 0;
-    int64_t n_E = 0, n_ab = 0;
+    int64_t n_E = 0, n_ab = 0, n_P = 0, n_rows = 0;
+    bool lin = false;   // forward-backward by a linear-domain sweep (decided in make_plan)
+    int band_bw = 0, band_sn = 0, band_m = 1;   // banded form: widest band / most positions (band_bw < 0: some graph is not banded)
     int Tlong = 0;
 };
 
@@ -1156,8 +1867,18 @@ int check_blob(const void* graph_host) {
 }
 
 // mode: 0 = forward-backward (alpha+beta arenas), 1 = tot only, 2 = viterbi (bp arena)
+struct RegCfg {
+    bool ok = false;
+    int threads = 0, R = 1, HD = 0, smax = 0;
+    size_t lds = 0;
+};
+RegCfg lin_config(const Plan& P);
+struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; };
+BandSel band_config(const Plan& P);
+
+// dbl_exact: WF_DOUBLE_ACC (k2 use_double_scores=True): exp/log in fp64 too, log-semiring sweep only
 int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V,
-              int num_seqs, size_t acc_bytes, int mode, Plan* P) {
+              int num_seqs, size_t acc_bytes, int mode, Plan* P, bool dbl_exact = false) {
     int rc = check_blob(graph_host);
     if (rc) return rc;
     if (B < 1 || !seg || V < 1) return wf_fail(WF_EINVAL, "bad B/seg/V");
@@ -1166,7 +1887,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     if (!utt2fsa && G != B) return wf_fail(WF_EINVAL, "graph has %d FSAs but %d segments (pass utt2fsa to share graphs)", G, B);
     P->B = B;
     P->utt.assign((size_t)B * WF_U_WORDS, 0);
-    int64_t nE = 0, nab = 0, row0 = 0;
+    int64_t nE = 0, nab = 0, nP = 0, row0 = 0;
     for (int i = 0; i < B; ++i) {
         const int g = utt2fsa ? utt2fsa[i] : i;
         if (g < 0 || g >= G) return wf_fail(WF_ERANGE, "utt2fsa[%d] = %d out of range", i, g);
@@ -1178,6 +1899,8 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         U[WF_U_FSA] = g; U[WF_U_SEQ] = b; U[WF_U_START] = st; U[WF_U_T] = T;
         U[WF_U_ALPHA] = nab; U[WF_U_BETA] = nab; U[WF_U_E] = nE; U[WF_U_ROW0] = row0;
         U[WF_U_OFFS] = row0 + i;   // sum of (T+1) over the utterances before this one
+        U[WF_U_P] = nP;
+        nP += (int64_t)T * I[WF_I_K];
         U[WF_U_S] = I[WF_I_S]; U[WF_U_A] = I[WF_I_A]; U[WF_U_K] = I[WF_I_K]; U[WF_U_DIRECT] = I[WF_I_DIRECT];
         U[WF_U_MAXLABDEG] = I[WF_I_MAXLAB_DEG];
         U[WF_U_LAB_OFF] = I[WF_I_LAB_OFF]; U[WF_U_LAB_SRC] = I[WF_I_LAB_SRC]; U[WF_U_LAB_DST] = I[WF_I_LAB_DST];
@@ -1197,9 +1920,13 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         if (I[WF_I_NOVER_OUT] > 1) P->reg_ok_out = false;
         if (I[WF_I_NOVER_IN] == 1) P->over_deg_in = std::max(P->over_deg_in, (int)I[WF_I_MAXIN]);
         if (I[WF_I_NOVER_OUT] == 1) P->over_deg_out = std::max(P->over_deg_out, (int)I[WF_I_MAXOUT]);
+        if (I[WF_I_BAND_BW] < 0) P->band_bw = -1;
+        else if (P->band_bw >= 0) P->band_bw = std::max(P->band_bw, (int)I[WF_I_BAND_BW]);
+        P->band_sn = std::max(P->band_sn, (int)I[WF_I_S] - 1);
+        P->band_m = std::max(P->band_m, (int)I[WF_I_BAND_M]);
         row0 += T;
     }
-    P->n_E = nE; P->n_ab = nab;
+    P->n_E = nE; P->n_ab = nab; P->n_P = nP; P->n_rows = row0;
     size_t o = 0;
     P->off_utt = o; o = align_up(o + sizeof(int64_t) * WF_U_WORDS * B, 256);
     P->off_seq2utt = o; o = align_up(o + sizeof(int32_t) * std::max(num_seqs, 1), 256);
@@ -1209,6 +1936,13 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     P->off_tot2 = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
     if (mode == 0) {
+        P->lin = acc_bytes == 8 && !dbl_exact && (band_config(*P).ok || lin_config(*P).ok);
+        P->off_ctot2 = o; o = align_up(o + sizeof(double) * B, 256);
+        P->off_flag = o; o = align_up(o + sizeof(int32_t) * B, 256);
+        if (P->lin) {
+            P->off_P = o; o = align_up(o + sizeof(double) * (size_t)nP, 256);
+            P->off_cmax = o; o = align_up(o + sizeof(double) * (size_t)std::max<int64_t>(row0, 1), 256);
+        }
         P->off_alpha = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
         P->off_beta = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
         P->off_aoff = o; o = align_up(o + sizeof(double) * (size_t)(row0 + B), 256);
@@ -1224,9 +1958,9 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
 // around each kernel of the last wf_fb_logsum / wf_fb_backward call of this thread.
 struct Timing {
     bool on = false;
-    hipEvent_t ev[7] = {};   // t0 | gather | sweep | (post t0) | post | zero t0 | zero t1
+    hipEvent_t ev[8] = {};   // t0 | gather | sweep | (post t0) | post | zero t0 | zero t1 | check + fallback
     bool made = false;
-    bool have_fwd = false, have_post = false, have_zero = false;
+    bool have_fwd = false, have_post = false, have_zero = false, have_check = false;
 };
 thread_local Timing g_tm;
 int tm_record(int i, hipStream_t st) {
@@ -1289,6 +2023,18 @@ SweepCfg sweep_config(const Plan& P, size_t acc_bytes) {
     return c;
 }
 
+// the fallback re-run: no LDS staging of arcs or emissions (rare path, any size that the linear sweep takes)
+SweepCfg sweep_config_minimal(const Plan& P, size_t acc_bytes) {
+    SweepCfg c{};
+    c.threads = std::min(kMaxThreads, std::max(64, (int)align_up(P.smax, 64)));
+    c.smax = (int)align_up(P.smax, 4);
+    c.hcap = std::max(1, std::min(kMaxHeavy, P.hmax));
+    c.kpad = std::max(P.kmax, 1);
+    c.estage = false; c.arcs_lds = false; c.chunk = 0; c.arcs_words = 0;
+    c.lds = 2 * (size_t)c.smax * acc_bytes + (size_t)c.hcap * 16 * 2 * acc_bytes + (size_t)c.hcap * 16 * 4;
+    return c;
+}
+
 template <typename Acc, typename Sum, int MODE>
 int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
     const int ndir = (MODE == M_FB) ? 2 : 1;
@@ -1313,12 +2059,6 @@ int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
 }
 
 // ---- register-resident quad sweep: eligibility and launch
-struct RegCfg {
-    bool ok = false;
-    int threads = 0, R = 1, HD = 0, smax = 0;
-    size_t lds = 0;
-};
-
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -1343,10 +2083,86 @@ RegCfg reg_config(const Plan& P, bool both_dirs) {
     return c;
 }
 
+// linear-domain forward-backward sweep: lane = state, so S <= 1024; every state but (at most) one per
+// direction has <= WF_REG_DEG arcs; the exceptional state's arcs fit HD <= 2 per lane
+RegCfg lin_config(const Plan& P) {
+    RegCfg c;
+    static const int no_lin = env_int("WF_NO_LIN_SWEEP", 0);
+    if (no_lin) return c;
+    if (P.smax > kMaxThreads || !P.reg_ok_in || !P.reg_ok_out) return c;
+    c.threads = std::max(64, (int)align_up(P.smax, 64));
+    const int od = std::max(P.over_deg_in, P.over_deg_out);
+    c.HD = (od + c.threads - 1) / c.threads;
+    if (c.HD > 2) return c;
+    c.smax = (int)align_up(P.smax, 4);
+    c.lds = 2 * (size_t)c.smax * 8 + 16 * 8 + 16 * 4;
+    c.ok = true;
+    return c;
+}
+
+// frames per rescale group = ring depth of the kernel variant launch_sweep_lin() picks
+int lin_group(const RegCfg& c) { return c.threads <= 256 ? 8 : 4; }
+
+// banded wave sweep: every graph of the call is banded and fits one wavefront; picks the instantiation
+BandSel band_config(const Plan& P) {
+    BandSel b;
+    static const int no_band = env_int("WF_NO_BAND_SWEEP", 0);
+    if (no_band || P.band_bw < 0 || P.band_sn < 1) return b;
+    b.BW = P.band_bw <= 2 ? 2 : 4;
+    b.R = std::max(b.BW, (P.band_sn + 63) / 64);
+    if (b.R > WF_BAND_MAX_R) return b;
+    b.grp = (b.R * (b.BW + 1) <= 12) ? 8 : 4;
+    b.M = P.band_m <= 1 ? 1 : 2;
+    b.ok = true;
+    return b;
+}
+
+template <int R, int BW, int MM>
+int launch_band_one(const SweepArgs& a, int B, hipStream_t st) {
+    using Cfg = BandCfg<R, BW>;
+    auto k = sweep_band_kernel<R, BW, MM>;
+    if (Cfg::LDS > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+    hipLaunchKernelGGL(k, dim3(B * 2), dim3(Cfg::NT), Cfg::LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st) {
+    static const int prof = env_int("WF_SWEEP_PROFILE", 0);
+    a.ablate = prof;
+#define WF_BAND_CASE(RR, WW)                                                                     \
+    if (b.BW == WW && b.R == RR) return b.M == 1 ? launch_band_one<RR, WW, 1>(a, B, st) : launch_band_one<RR, WW, 2>(a, B, st)
+    WF_BAND_CASE(2, 2);
+    WF_BAND_CASE(3, 2);
+    WF_BAND_CASE(4, 2);
+    WF_BAND_CASE(4, 4);
+#undef WF_BAND_CASE
+    return wf_fail(WF_EUNSUPPORTED, "internal: no banded sweep for R=%d BW=%d", b.R, b.BW);
+}
+
+int launch_sweep_lin(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
+    dim3 grid(B * 2), block(c.threads);
+    a.smax = c.smax;
+    static const int prof = env_int("WF_SWEEP_PROFILE", 0);
+    a.ablate = prof;   // bit 8: print cycles per step; bits 1/2/4: ablations (row stores / ring refills / rescale) for timing only
+    // two register budgets: workgroups of <= 256 lanes may use up to 512 VGPRs per lane
+#define WF_LAUNCH_LIN(HH)                                                                             \
+    do {                                                                                              \
+        if (c.threads <= 256) hipLaunchKernelGGL((sweep_lin_kernel<HH, 256>), grid, block, c.lds, st, a); \
+        else hipLaunchKernelGGL((sweep_lin_kernel<HH, kMaxThreads>), grid, block, c.lds, st, a);        \
+    } while (0)
+    if (c.HD == 0) WF_LAUNCH_LIN(0);
+    else if (c.HD == 1) WF_LAUNCH_LIN(1);
+    else WF_LAUNCH_LIN(2);
+#undef WF_LAUNCH_LIN
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
 template <int MODE>
 int launch_sweep_quad(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
-    const int ndir = (MODE == M_FB) ? 2 : 1;
-    dim3 grid(B * ndir), block(c.threads);
+    dim3 grid(B), block(c.threads);
     a.smax = c.smax;
     static const int prof = env_int("WF_SWEEP_PROFILE", 0);
     a.ablate = prof ? 8 : 0;
@@ -1375,7 +2191,8 @@ extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2
     const size_t ab = 8;  // log semiring: alpha/beta are always kept in fp64
     int maxseq = 0;
     if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, (need_grad || (flags & WF_KEEP_AB)) ? 0 : 1, &P);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, (need_grad || (flags & WF_KEEP_AB)) ? 0 : 1, &P,
+                       (flags & WF_DOUBLE_ACC) != 0);
     if (rc) return rc;
     *bytes = P.total + 256;
     return WF_OK;
@@ -1413,6 +2230,14 @@ int build_seq2utt(const int32_t* seg, int B, int num_seqs, std::vector<int32_t>*
 
 int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                   int64_t strideB, int64_t strideT, hipStream_t st) {
+    if (P.lin) {
+        GatherLinArgs g{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), lp, strideB, strideT,
+                        (float*)(ws + P.off_E), (double*)(ws + P.off_P), (double*)(ws + P.off_cmax),
+                        (int32_t*)(ws + P.off_flag)};
+        hipLaunchKernelGGL(gather_lin_kernel, dim3(std::max(P.Tlong, 1), P.B), dim3(64), 0, st, g);
+        HIP_TRY(hipGetLastError());
+        return WF_OK;
+    }
     if (!P.any_compact) return WF_OK;
     GatherArgs g{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), lp, strideB, strideT,
                  (float*)(ws + P.off_E), P.B};
@@ -1425,9 +2250,15 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
 
 int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                 int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
-                float* grad, bool skip_zero, bool ab_float, hipStream_t st) {
+                float* grad, bool skip_zero, hipStream_t st) {
     PostArgs q{};
-    q.ab_float = ab_float ? 1 : 0;
+    {
+        const BandSel bs = band_config(P);
+        q.lin = !P.lin ? 0 : (bs.ok ? bs.grp : lin_group(lin_config(P)));
+        q.lag = bs.ok ? 0 : 1;
+    }
+    q.ctot2 = (const double*)(ws + P.off_ctot2); q.cmax = (const double*)(ws + P.off_cmax);
+    q.flag = (const int32_t*)(ws + P.off_flag);
     q.aoff = (const double*)(ws + P.off_aoff); q.boff = (const double*)(ws + P.off_boff);
     q.blob = (const int32_t*)graph_dev; q.utt = (const int64_t*)(ws + P.off_utt);
     q.seq2utt = (const int32_t*)(ws + P.off_seq2utt);
@@ -1440,7 +2271,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     q.acap = (P.maxlabdeg > 8 && P.amax <= 8192) ? (int)align_up(P.amax, 4) : 0;
     q.skip_zero = skip_zero ? 1 : 0;
     size_t lds = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
-    if (ab_float && skip_zero && !getenv("WF_NO_POST_SMALL") && P.all_compact && P.amax >= 1 && P.amax <= 64 * kPS && P.smax <= 64 * kPS &&
+    if (P.lin && skip_zero && !getenv("WF_NO_POST_SMALL") && P.all_compact && P.amax >= 1 && P.amax <= 64 * kPS && P.smax <= 64 * kPS &&
         P.kmax_compact <= 64 * kPS && q.ecap > 0) {
         q.acap = (int)align_up(P.amax, 4);
         size_t lds2 = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
@@ -1477,7 +2308,7 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     const bool need_ab = grad || (flags & WF_KEEP_AB);
     const size_t ab = 8;
     Plan P;
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, need_ab ? 0 : 1, &P);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, need_ab ? 0 : 1, &P, dbl);
     if (rc) return rc;
     for (int i = 0; i < B; ++i)
         if (seg[3 * i + 1] + seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d exceeds Tmax=%d", i, Tmax);
@@ -1487,7 +2318,7 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     if (need_ab) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
     rc = upload_tables(P, ws, need_ab ? seq2utt.data() : nullptr, num_seqs, st);
     if (rc) return rc;
-    g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = false;
+    g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = g_tm.have_check = false;
     // Fork: zero-fill the gradient box on the side stream while the sweeps (which occupy only 2B
     // workgroups) run; post_kernel then only scatters the K posteriors per row.
     const bool overlap = grad && P.any_compact && !getenv("WF_NO_OVERLAP");
@@ -1539,17 +2370,38 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
     a.aoff = (double*)(ws + P.off_aoff); a.boff = (double*)(ws + P.off_boff);
     a.tot2 = (double*)(ws + P.off_tot2);
-    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, need_ab);
-    if (rc_.ok) rc = need_ab ? launch_sweep_quad<M_FB>(rc_, a, B, st) : launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
-    else if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);
-    else rc = dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
-    if (rc) return rc;
-    if ((rc = tm_record(2, st))) return rc;
+    a.P = (const double*)(ws + P.off_P); a.cmax = (const double*)(ws + P.off_cmax); a.ctot2 = (double*)(ws + P.off_ctot2);
+    if (P.lin) {
+        // linear-domain sweep, then the row identity check and the log-semiring re-run of whatever failed it
+        const BandSel bs = band_config(P);
+        rc = bs.ok ? launch_sweep_band(bs, a, B, st) : launch_sweep_lin(lin_config(P), a, B, st);
+        if (rc) return rc;
+        if ((rc = tm_record(2, st))) return rc;
+        CheckArgs k{a.blob, a.utt, (const double*)a.alpha, (const double*)a.beta, a.aoff, a.boff, a.tot2, a.ctot2,
+                    (int32_t*)(ws + P.off_flag), bs.ok ? bs.grp : lin_group(lin_config(P)), bs.ok ? 0 : 1};
+        hipLaunchKernelGGL(check_kernel, dim3(P.Tlong + 1, B), dim3(64), 0, st, k);
+        HIP_TRY(hipGetLastError());
+        SweepCfg fc = sweep_config_minimal(P, ab);
+        SweepArgs fa = a;
+        fa.flag = (const int32_t*)(ws + P.off_flag);
+        fa.chunk = fc.chunk; fa.kpad = fc.kpad; fa.smax = fc.smax; fa.arcs_lds_words = 0; fa.hcap = fc.hcap;
+        rc = launch_sweep<double, float, M_FB>(fc, fa, B, st);
+        if (rc) return rc;
+        if ((rc = tm_record(7, st))) return rc;
+    } else {
+        RegCfg rc_ = (dbl || need_ab) ? RegCfg() : reg_config(P, false);
+        if (rc_.ok) rc = launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
+        else if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);
+        else rc = dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
+        if (rc) return rc;
+        if ((rc = tm_record(2, st))) return rc;
+    }
     g_tm.have_fwd = g_tm.on;
+    g_tm.have_check = g_tm.on && P.lin;
     if (grad) {
         if (overlap) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
         if ((rc = tm_record(3, st))) return rc;
-        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, rc_.ok, st);
+        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st);
         if (rc) return rc;
         if ((rc = tm_record(4, st))) return rc;
         g_tm.have_post = g_tm.on;
@@ -1559,11 +2411,15 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
 
 extern "C" int wf_timing_enable(int on) { g_tm.on = on != 0; g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = false; return WF_OK; }
 
-// ms[0..3] = gather, sweep, post, zero-fill kernel time of the last timed call(s); -1 = not measured.
-// Synchronises on the recorded events (a measurement aid, not part of the hot path).
+// ms[0..4] = gather, sweep, post, zero-fill, check + fallback kernel time of the last timed call(s);
+// -1 = not measured.  Synchronises on the recorded events (a measurement aid, not part of the hot path).
 extern "C" int wf_timing_read(float* ms) {
     if (!ms) return wf_fail(WF_EINVAL, "wf_timing_read: null");
-    ms[0] = ms[1] = ms[2] = ms[3] = -1.f;
+    ms[0] = ms[1] = ms[2] = ms[3] = ms[4] = -1.f;
+    if (g_tm.have_check) {
+        HIP_TRY(hipEventSynchronize(g_tm.ev[7]));
+        HIP_TRY(hipEventElapsedTime(&ms[4], g_tm.ev[2], g_tm.ev[7]));
+    }
     if (g_tm.have_fwd) {
         HIP_TRY(hipEventSynchronize(g_tm.ev[2]));
         HIP_TRY(hipEventElapsedTime(&ms[0], g_tm.ev[0], g_tm.ev[1]));
@@ -1588,15 +2444,15 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     if (!graph_dev || !log_probs || !tot || !grad || !workspace) return wf_fail(WF_EINVAL, "wf_fb_backward: null pointer");
     const bool dbl = flags & WF_DOUBLE_ACC;
     Plan P;
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P, dbl);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
-    (void)dbl; (void)tot;
+    (void)tot;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = tm_record(3, st))) return rc;
-    const bool ab_float = !dbl && reg_config(P, true).ok;   // same decision as the forward call made
-    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, false, ab_float, st);
+    // P.lin repeats the decision the forward call made; the fallback flags are still in the workspace
+    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, false, st);
     if (rc) return rc;
     if ((rc = tm_record(4, st))) return rc;
     g_tm.have_post = g_tm.on;
