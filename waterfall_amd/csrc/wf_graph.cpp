@@ -270,6 +270,11 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
         {
             const int Sn = S - 1;   // the super-final state has no emitting arcs
             I[WF_I_BAND_BW] = -1; I[WF_I_BAND_M] = 0;
+            {
+                int we = 1;
+                for (int a : p.em) { float w; memcpy(&w, &arcs[4 * a + 3], 4); if (w != 0.f) we = 0; }
+                I[WF_I_BAND_WE] = we;
+            }
             std::vector<int> indeg(Sn, 0), order, pos(Sn, -1);
             const int32_t* ooff = B + I[WF_I_OUT_OFF];
             const int32_t* odst = B + I[WF_I_OUT_DST];

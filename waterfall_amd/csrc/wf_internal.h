@@ -68,6 +68,7 @@ enum {
     WF_I_BANDF = 43,       // [S-1][BW+1][M] x {column, weight bits}: arcs INTO the state at p from p - d
     WF_I_BANDB = 44,       // same for the backward sweep in reversed positions p' = S-2-p:
                            // arcs OUT OF the state at p' to p' - d (reversed), i.e. to position p + d
+    WF_I_BAND_WE = 45,     // 1: every emitting arc has weight 0 ("weights elided": all training topologies)
 };
 // limits of the banded sweep (template instantiations in wf_kernels.hip)
 #define WF_BAND_MAX_BW 4
@@ -90,5 +91,6 @@ enum {
     WF_U_LABELS = 18,
     WF_U_OFFS = 19,  // element offset of this utterance's per-group scale offsets (<= T+1 doubles)
     WF_U_P = 20,     // element offset of the fp64 emission probabilities (linear-domain sweep)
+    WF_U_PP = 21,    // their row pitch in doubles: K rounded up to even, so that rows are 16-byte aligned
     WF_U_WORDS = 24,
 };

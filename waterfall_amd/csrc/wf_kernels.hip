@@ -915,7 +915,7 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
     // without arcs or an empty segment reads the utterance table (small integers = finite tiny
     // doubles) through a zero pitch.
     const double* pbase = p.P + uni(U[WF_U_P]);
-    int64_t ppitch = K;
+    int64_t ppitch = uni((int)U[WF_U_PP]);
     if (A == 0 || T == 0) { pbase = (const double*)U; ppitch = 0; }
     const int last_step = max(T - 1, 0);
     const int64_t pstep = dir ? -ppitch : ppitch;
@@ -1094,44 +1094,48 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
 
 // ------------------------------------------------------------------------------------------
 // Banded wave sweep: the linear-domain forward-backward recursion of a numerator graph with NO LDS
-// round trip and NO barrier on the critical path.
+// round trip of the state vector and NO barrier on the critical path.
 //
 // Every topo o transcript graph has a topological order of its states in which each arc goes from
 // position p - d to position p with 0 <= d <= BW <= 4 (wf_graph.cpp, WF_I_BAND_*).  ONE wavefront (the
 // chain wave) then carries the whole state vector in registers, R consecutive positions per lane:
 // the sources of a state are in the same lane or in lane - 1, fetched with a wave_shr:1 DPP move, and
-// a frame step is BW DPP moves + R*(BW+1) fp64 FMAs, about 70-100 cycles instead of the ~440 of the
-// LDS/barrier recursion (measured, tools/ubench/band.hip).  Everything else runs beside it on the
-// other three SIMDs of the CU (helper waves): the arc probabilities q[p][d] = sum_m exp(w_m) *
-// P_t[col_m] of the NEXT chunk of C frames go into an LDS double buffer (emissions prefetched one
-// more chunk ahead in registers), and the alpha rows of the PREVIOUS chunk go from an LDS double
-// buffer to the workspace.  Chain and helpers meet at one barrier per chunk.  The backward sweep is
-// the same code on the reversed order.  Rescaling (chain wave, once per chunk) and the row check /
-// fallback are as for sweep_lin_kernel.
+// a frame step is BW DPP moves + R*(BW+1) fp64 FMAs.  The arc probabilities come from emission rows
+// that a second wavefront (the stager) copies, coalesced and two chunks of C frames ahead, from the
+// workspace into an LDS double buffer; the chain wave reads P_t[column] of its R*(BW+1) cells from
+// there one step ahead of their use.  Chain and stager meet at one barrier per chunk.  The alpha rows
+// leave the chain wave as plain stores (never waited for).  The backward sweep is the same code on
+// the reversed order.  Rescaling (once per chunk, decided by the stager from the exponents of the
+// previous chunk's last row) and the row check / fallback are as for sweep_lin_kernel.
+// Measured (cfg3, MI355X): ~NNN cycles per frame step against ~440 for sweep_lin_kernel.
 // ------------------------------------------------------------------------------------------
-template <int R, int BW>
-struct BandCfg {
-    static constexpr int NQ = R * (BW + 1);            // coefficients per lane per frame
-    static constexpr int NQP = (NQ + 1) / 2;           // ... read as 16-byte pairs
-    static constexpr int NH = (NQ % 3 == 0) ? 3 : 4;   // helper waves (NQ must split evenly over them)
-    static constexpr int OWN = NQ / NH;                // (coefficient, lane) cells a helper lane owns
-    static constexpr int C = (NQ <= 12) ? 8 : 4;       // frames per chunk
-    static constexpr int NT = 64 * (1 + NH);
-    static constexpr size_t QBYTES = (size_t)C * NQP * 64 * 16;   // one chunk of coefficients
-    static constexpr size_t LDS = 2 * QBYTES + 2 * 64 * 4 + 16;   // + per-lane exponents (x2) + shift words
-    static_assert(NQ % NH == 0, "coefficients must split evenly over the helper waves");
-    static_assert(BW <= R, "sources must sit in the same lane or the previous one");
-};
+constexpr int kBandKP = 192;   // row pitch of the staged emission rows; a banded graph uses < kBandKP label columns
+constexpr int kBandC = 16;     // frames per chunk
 
-// MM: arcs per (position, distance) cell the instantiation handles (1: deterministic topologies)
-template <int R, int BW, int MM>
-__global__ void __launch_bounds__(64 * (1 + ((R * (BW + 1)) % 3 == 0 ? 3 : 4))) sweep_band_kernel(SweepArgs p) {
-    using Cfg = BandCfg<R, BW>;
-    constexpr int NQ = Cfg::NQ, NQP = Cfg::NQP, NH = Cfg::NH, OWN = Cfg::OWN, C = Cfg::C;
-    static_assert(MM >= 1 && MM <= WF_BAND_MAX_M, "cell capacity");
+// wave_shr:1 of a double: lane i receives lane i-1's value, lane 0 receives 0 (bound_ctrl)
+__device__ __forceinline__ double wave_shr1_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr size_t kBandPBytes = (size_t)kBandC * kBandKP * 8;          // one chunk of staged emission rows
+constexpr size_t kBandLdsUsed = 2 * kBandPBytes + 2 * 64 * 4 + 16;    // + per-lane exponents (x2) + shift words
+// Requested: more than half of the CU's 160 KiB, so that no two sweep workgroups share a CU (two chain waves
+// on one SIMD would halve each other's issue rate; there are only 2B workgroups for 256 CUs)
+constexpr size_t kBandLds = kBandLdsUsed > 84 * 1024 ? kBandLdsUsed : 84 * 1024;
+
+// MM: arcs per (position, distance) cell (1: deterministic topologies); WE: every arc weight is 0 and
+// MM == 1, so a cell's probability is the staged emission itself (no multiply)
+template <int R, int BW, int MM, bool WE>
+__global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
+    constexpr int NQ = R * (BW + 1), C = kBandC;
+    static_assert(MM >= 1 && MM <= WF_BAND_MAX_M && (!WE || MM == 1), "cell capacity");
+    static_assert(BW <= R, "sources must sit in the same lane or the previous one");
     extern __shared__ __align__(16) unsigned char smem[];
-    // LDS: coefficient double buffer [2][C][NQP][64] x 16 B, then 2 x 64 exponent words, then 2 shift words
-    int* ebuf = (int*)(smem + 2 * Cfg::QBYTES);
+    const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+    // LDS: staged emission rows [2][C][kBandKP] x 8 B | 2 x 64 exponent words | 2 shift words
+    int* ebuf = (int*)(smem + 2 * kBandPBytes);
     int* shw = ebuf + 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = blockIdx.x >> 1, dir = blockIdx.x & 1;
@@ -1150,104 +1154,137 @@ __global__ void __launch_bounds__(64 * (1 + ((R * (BW + 1)) % 3 == 0 ? 3 : 4))) 
         return;
     }
     const int Sn = S - 1;   // positions: every state but the super-final one
-    const int gbw = uni(I[WF_I_BAND_BW]), gm = uni(I[WF_I_BAND_M]);
-    const int32_t* order = blob + uni(I[WF_I_BAND_ORDER]);
-    const int32_t* tab = blob + uni(I[dir ? WF_I_BANDB : WF_I_BANDF]);
-    const float* fb = (const float*)(blob + uni(I[WF_I_FINB_LOG]));
     const int nc = (T + C - 1) / C;
-    double* arena = (double*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
-    double* goff = (dir ? p.boff : p.aoff) + uni(U[WF_U_OFFS]);
     if (tid < 2) shw[tid] = tid == 0 ? kLinBias : 0;   // chunk 0: the initial vector's maximum is 1; chunk 1: nothing measured yet
 
     if (wave == 0) {
         // =============================== chain wave ===============================
+        const int gbw = uni(I[WF_I_BAND_BW]), gm = uni(I[WF_I_BAND_M]);
+        const int32_t* order = blob + uni(I[WF_I_BAND_ORDER]);
+        const int32_t* tab = blob + uni(I[dir ? WF_I_BANDB : WF_I_BANDF]);
+        const float* fb = (const float*)(blob + uni(I[WF_I_FINB_LOG]));
+        double* arena = (double*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
+        double* goff = (dir ? p.boff : p.aoff) + uni(U[WF_U_OFFS]);
         double a[R];
-        unsigned soff[R];   // byte offset of the state inside an alpha row; padding positions write the
-                            // (unused) super-final column, so that no store needs an exec mask
+        int sidx[R];   // column of the state inside an alpha row; padding positions write the (unused)
+                       // super-final column, so that no store needs an exec mask
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int pp = lane * R + r;
             int st = -1;
             if (pp < Sn) st = order[dir ? Sn - 1 - pp : pp];
             a[r] = st < 0 ? 0.0 : (dir ? exp((double)fb[st]) : (st == 0 ? 1.0 : 0.0));
-            soff[r] = (unsigned)(st < 0 ? S - 1 : st) * 8u;
-            *(double*)((char*)(arena + (int64_t)(dir ? T : 0) * S) + soff[r]) = a[r];   // alpha_0 / beta_T
+            sidx[r] = st < 0 ? S - 1 : st;
+            arena[(int64_t)(dir ? T : 0) * S + sidx[r]] = a[r];   // alpha_0 / beta_T
+        }
+        // this lane's cells: byte offset of the arc's column inside a staged row (empty cell: column K,
+        // which the stager keeps at 0) and exp(weight)
+        unsigned coff[NQ][MM];
+        double cw[NQ][MM];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int r = j / (BW + 1), d = j % (BW + 1);
+            const int pp = lane * R + r;
+            const bool cell = pp < Sn && d <= gbw;
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                int col = K;
+                float w = 0.f;
+                if (cell && m < gm) {
+                    const int32_t* ent = tab + (((size_t)pp * (gbw + 1) + d) * gm + m) * 2;
+                    w = __int_as_float(ent[1]);
+                    col = (w == -INFINITY) ? K : ent[0];   // an unused slot of the cell
+                    if (w == -INFINITY) w = 0.f;
+                }
+                coff[j][m] = (unsigned)col * 8u;
+                cw[j][m] = exp((double)w);
+            }
         }
         if (lane == 0) goff[0] = 0.0;
         double cum = 0.0;   // cumulative power-of-two shift (log2 units) carried by the rows
         // row written by step 0: alpha_1 / beta_{T-1}; then +-S doubles per step
-        char* srow = (char*)(arena + (int64_t)(dir ? (T - 1) : 1) * S);
-        const int64_t sstep = (dir ? -(int64_t)S : (int64_t)S) * 8;
+        double* srow = arena + (int64_t)(dir ? (T - 1) : 1) * S;
+        const int64_t sstep = dir ? -(int64_t)S : (int64_t)S;
         const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        auto load_q = [&](const char* qb, const int k, d2 (&q)[NQP]) __attribute__((always_inline)) {
+        // q[j] = probability of cell j in the frame at row k of the staged chunk
+        auto load_q = [&](const unsigned char* pb, const int k, double (&q)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NQP; ++j) q[j] = *(const d2*)(qb + (size_t)(k * NQP + j) * 1024);
+            for (int j = 0; j < NQ; ++j) {
+                if (WE) {
+                    q[j] = *(const double*)(pb + (size_t)k * kBandKP * 8 + coff[j][0]);
+                } else {
+                    double v = cw[j][0] * *(const double*)(pb + (size_t)k * kBandKP * 8 + coff[j][0]);
+#pragma unroll
+                    for (int m = 1; m < MM; ++m) v = fma(cw[j][m], *(const double*)(pb + (size_t)k * kBandKP * 8 + coff[j][m]), v);
+                    q[j] = v;
+                }
+            }
         };
-        auto step = [&](const d2 (&q)[NQP]) __attribute__((always_inline)) {
+        auto step = [&](const double (&q)[NQ]) __attribute__((always_inline)) {
             double nb[BW];   // nb[j]: the state at position lane*R - 1 - j (slot R-1-j of lane - 1)
 #pragma unroll
-            for (int j = 0; j < BW; ++j) nb[j] = dpp_d<0x138, 0xf>(a[R - 1 - j]);   // wave_shr:1, lane 0 receives 0
+            for (int j = 0; j < BW; ++j) nb[j] = wave_shr1_d(a[R - 1 - j]);
             double an[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 double v = 0.0;
 #pragma unroll
                 for (int d = 0; d <= BW; ++d) {
-                    const int jq = r * (BW + 1) + d;
-                    const double qq = (jq & 1) ? q[jq >> 1].y : q[jq >> 1].x;
                     const double sv = (r - d >= 0) ? a[r - d >= 0 ? r - d : 0] : nb[d - r - 1 >= 0 ? d - r - 1 : 0];
-                    v = (d == 0) ? sv * qq : fma(sv, qq, v);
+                    v = (d == 0) ? sv * q[r * (BW + 1)] : fma(sv, q[r * (BW + 1) + d], v);
                 }
                 an[r] = v;
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 a[r] = an[r];
-                if (!(p.ablate & 4)) *(double*)(srow + soff[r]) = an[r];
+                srow[sidx[r]] = an[r];
             }
             srow += sstep;
         };
-        for (int c = 0; c < nc; ++c) {
-            __syncthreads();   // the coefficients of chunk c are in place
-            const char* qb = (const char*)smem + (size_t)(c & 1) * Cfg::QBYTES + lane * 16;
-            d2 q0[NQP], q1[NQP];
-            load_q(qb, 0, q0);
-            {   // rescale by the power of two the helpers derived from the row two chunks back
-                const int sh = uni(shw[c & 1]);
+        auto open_chunk = [&](const int c) __attribute__((always_inline)) {
+            // rescale by the power of two the stager derived from the row two chunks back
+            const int sh = uni(shw[c & 1]);
 #pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = ldexp(a[r], sh);
-                cum += (double)sh;
-                if (lane == 0) goff[c + 1] = cum;
+            for (int r = 0; r < R; ++r) a[r] = ldexp(a[r], sh);
+            cum += (double)sh;
+            if (lane == 0) goff[c + 1] = cum;
+        };
+        const int nfull = T / C;
+        for (int c = 0; c < nfull; ++c) {   // full chunks: straight-line steps, probabilities read one step ahead
+            __syncthreads();   // the rows of chunk c are staged
+            const unsigned char* pb = smem + (size_t)(c & 1) * kBandPBytes;
+            double q0[NQ], q1[NQ];
+            load_q(pb, 0, q0);
+            open_chunk(c);
+#pragma unroll
+            for (int k = 0; k < C; k += 2) {
+                load_q(pb, k + 1, q1);
+                step(q0);
+                if (k + 2 < C) load_q(pb, k + 2, q0);
+                step(q1);
             }
-            const int nk = min(C, T - c * C);
-            if (nk == C) {   // full chunk: no per-step test; the next step's coefficients are read a step ahead
-#pragma unroll
-                for (int k = 0; k < C; k += 2) {
-                    load_q(qb, k + 1, q1);
-                    step(q0);
-                    if (k + 2 < C) load_q(qb, k + 2, q0);
-                    step(q1);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    if (k < nk) {
-                        if (k > 0) load_q(qb, k, q0);
-                        step(q0);
-                    }
-                }
-            }
-            {   // this lane's largest exponent, for the helpers' next rescale decision
+            {   // this lane's largest exponent, for the stager's next rescale decision
                 int e = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) e = max(e, f64_exp_field(a[r]));
                 ebuf[(c & 1) * 64 + lane] = e;
             }
         }
+        if (nfull < nc) {   // the last, partial chunk
+            __syncthreads();
+            const unsigned char* pb = smem + (size_t)(nfull & 1) * kBandPBytes;
+            open_chunk(nfull);
+            const int nk = T - nfull * C;
+            for (int k = 0; k < nk; ++k) {
+                double q0[NQ];
+                load_q(pb + (size_t)k * kBandKP * 8, 0, q0);
+                step(q0);
+            }
+        }
         __syncthreads();
-        if ((p.ablate & 8) && blockIdx.x == 0 && lane == 0)
-            printf("sweep_band<%d,%d,%d>: T=%d cycles/step=%.1f\n", R, BW, MM, T, (double)(__builtin_amdgcn_s_memtime() - clk0) / max(T, 1));
+        if ((p.ablate & 8) && (blockIdx.x == 0 || (p.ablate & 16)) && lane == 0)
+            printf("sweep_band<%d,%d,%d,%d> wg %d: T=%d cycles/step=%.1f setup=%llu cycles total=%llu\n", R, BW, MM, (int)WE, (int)blockIdx.x, T, (double)(__builtin_amdgcn_s_memtime() - clk0) / max(T, 1), clk0 - tstart, __builtin_amdgcn_s_memtime() - tstart);
         if (dir == 0) {
             // total = sum over positions of alpha_T * exp(final weight), then undo the scaling
             double part = 0.0;
@@ -1272,81 +1309,95 @@ __global__ void __launch_bounds__(64 * (1 + ((R * (BW + 1)) % 3 == 0 ? 3 : 4))) 
             }
         }
     } else {
-        // =============================== helper waves ===============================
-        const int h = tid - 64;
-        // the (coefficient, lane) cells this lane produces: cell e = h + i*NH*64 -> coefficient e / 64 of lane e % 64
-        unsigned coff[OWN][MM];   // byte offset of the arc's column inside a P row
-        double cw[OWN][MM];       // exp(arc weight); 0 for an empty cell
-        unsigned qoff[OWN];       // byte offset of the cell inside one frame's coefficient block
-#pragma unroll
-        for (int i = 0; i < OWN; ++i) {
-            const int e = h + i * NH * 64;
-            const int j = e >> 6, ln = e & 63;
-            const int r = j / (BW + 1), d = j % (BW + 1);
-            const int pp = ln * R + r;
-            const bool cell = pp < Sn && d <= gbw;
-            qoff[i] = (unsigned)(((j >> 1) * 64 + ln) * 16 + (j & 1) * 8);
-#pragma unroll
-            for (int m = 0; m < MM; ++m) {
-                int col = 0;
-                float w = -INFINITY;
-                if (cell && m < gm) {
-                    const int32_t* ent = tab + (((size_t)pp * (gbw + 1) + d) * gm + m) * 2;
-                    col = ent[0];
-                    w = __int_as_float(ent[1]);
-                }
-                coff[i][m] = (unsigned)col * 8u;
-                cw[i][m] = exp((double)w);
-            }
-        }
-        const char* pbase = (const char*)(p.P + uni(U[WF_U_P]));
-        int64_t ppitch = (int64_t)K * 8;
-        if (A == 0 || T == 0) { pbase = (const char*)U; ppitch = 0; }   // finite dummies (the utterance table)
+        // =============================== stager wave ===============================
+        // a graph without arcs or an empty segment has no emission rows: read the utterance table (small
+        // integers = finite tiny doubles) through a zero pitch instead, so that every load stays unconditional
+        const bool has_p = A > 0 && T > 0;
+        const double* pbase = has_p ? p.P + uni(U[WF_U_P]) : (const double*)U;
+        const int64_t ppitch = has_p ? uni((int)U[WF_U_PP]) : 0;
         const int last_step = max(T - 1, 0);
-        double pre[C][OWN][MM];
-        auto issue = [&](const int c) __attribute__((always_inline)) {
+        constexpr int KVMAX = (kBandKP + 127) / 128;   // 128-column pieces per row: one 16-byte load per lane each
+        int lcol[KVMAX];   // first of this lane's two columns of each piece, clamped into the row: every load is
+                           // unconditional (a load under a run-time condition makes hipcc branch around it and
+                           // drain vmcnt per element)
+#pragma unroll
+        for (int v = 0; v < KVMAX; ++v) lcol[v] = has_p ? min(128 * v + 2 * lane, (int)ppitch - 2) : 0;   // even: 16-byte aligned; the pad column of an odd K is readable
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        unsigned loff[KVMAX];   // byte offset of the lane's pair inside a row
+#pragma unroll
+        for (int v = 0; v < KVMAX; ++v) loff[v] = (unsigned)lcol[v] * 8u;
+        // Two register sets: the rows of a chunk are loaded two chunks before they are staged (the measured
+        // load-to-use latency here is ~2 us, more than one chunk of the chain wave's time).
+        d2 preA[C][KVMAX], preB[C][KVMAX];
+        auto issue = [&](const int c, d2 (&pre)[C][KVMAX]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < C; ++k) {
-                const int s = min(c * C + k, last_step);
-                const char* row = pbase + (int64_t)(dir ? T - 1 - s : s) * ppitch;
+                const int s = min(c * C + k, last_step);   // frames past the end repeat the last one
+                const char* row = (const char*)(pbase + (int64_t)(dir ? T - 1 - s : s) * ppitch);   // scalar
 #pragma unroll
-                for (int i = 0; i < OWN; ++i)
-#pragma unroll
-                    for (int m = 0; m < MM; ++m) pre[k][i][m] = *(const double*)(row + coff[i][m]);
+                for (int v = 0; v < KVMAX; ++v) pre[k][v] = *(const d2*)(row + loff[v]);
             }
         };
-        auto produce = [&](const int c) __attribute__((always_inline)) {
-            char* qb = (char*)smem + (size_t)(c & 1) * Cfg::QBYTES;
+        // registers -> staged rows of chunk c (column K of every row is the zero that empty cells read)
+        auto stage = [&](const int c, const d2 (&pre)[C][KVMAX]) __attribute__((always_inline)) {
+            unsigned char* pb = smem + (size_t)(c & 1) * kBandPBytes;
+            // whole pairs (16-byte writes; an odd K's last pair carries the unused pad column), piece by piece so
+            // that the exec mask changes once per piece; then the zero column, which overwrites that pad
 #pragma unroll
-            for (int k = 0; k < C; ++k)
+            for (int v = 0; v < KVMAX; ++v) {
+                if (128 * v + 2 * lane < K) {   // not a clamped duplicate
 #pragma unroll
-                for (int i = 0; i < OWN; ++i) {
-                    double q = cw[i][0] * pre[k][i][0];
-#pragma unroll
-                    for (int m = 1; m < MM; ++m) q = fma(cw[i][m], pre[k][i][m], q);
-                    *(double*)(qb + (size_t)k * NQP * 1024 + qoff[i]) = q;
+                    for (int k = 0; k < C; ++k) *(d2*)(pb + (size_t)k * kBandKP * 8 + loff[v]) = pre[k][v];
                 }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < C; ++k) *(double*)(pb + ((size_t)k * kBandKP + K) * 8) = 0.0;
+            }
         };
+        auto decide = [&](const int c) __attribute__((always_inline)) {
+            // ebuf holds the exponents at the end of chunk c-1, before the shift shw[c&1] that chunk c
+            // applies: decide the shift of chunk c+1 so that the maximum returns to 2^kLinBias
+            const int e = wave_max_i(ebuf[((c - 1) & 1) * 64 + lane]);
+            const int sh_c = uni(shw[c & 1]);
+            const int sh = e > 0 ? (1023 + kLinBias) - (e + sh_c) : 0;
+            if (lane == 0) shw[(c + 1) & 1] = sh;
+        };
+        // Schedule (iteration c runs between barrier c and barrier c+1, beside the chain's chunk c): stage(c+1)
+        // from the register set of its parity (loaded during iteration c-2), then issue(c+3) into the same set.
+        // Even chunks use set A, odd chunks set B.
         if (nc > 0) {
-            issue(0);
-            produce(0);
-            if (nc > 1) issue(1);
+            issue(0, preA);
+            if (nc > 1) issue(1, preB);
+            stage(0, preA);
+            if (nc > 2) issue(2, preA);
         }
-        for (int c = 0; c <= nc; ++c) {
-            __syncthreads();
-            if (c + 1 < nc && !(p.ablate & 2)) {
-                produce(c + 1);
-                if (c + 2 < nc) issue(c + 2);
+        unsigned long long t_bar = 0, t_stage = 0, t_issue = 0;
+        for (int c = 0; c <= nc; c += 2) {
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();
+            __syncthreads();   // barrier c (c even)
+            const unsigned long long tb = __builtin_amdgcn_s_memtime();
+            t_bar += tb - ta;
+            if (c + 1 < nc) {
+                stage(c + 1, preB);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                const unsigned long long tc = __builtin_amdgcn_s_memtime();
+                if (c + 3 < nc) issue(c + 3, preB);
+                const unsigned long long td = __builtin_amdgcn_s_memtime();
+                t_stage += tc - tb; t_issue += td - tc;
             }
-            if (wave == 1 && c >= 1) {
-                // ebuf holds the exponents at the end of chunk c-1, before the shift shw[c&1] that chunk c
-                // applies: decide the shift of chunk c+1 so that the maximum returns to 2^kLinBias
-                const int e = wave_max_i(ebuf[((c - 1) & 1) * 64 + lane]);
-                const int sh_c = uni(shw[c & 1]);
-                const int sh = e > 0 ? (1023 + kLinBias) - (e + sh_c) : 0;
-                if (lane == 0) shw[(c + 1) & 1] = sh;
+            if (c >= 1) decide(c);
+            if (c + 1 <= nc) {
+                __syncthreads();   // barrier c+1
+                if (c + 2 < nc) {
+                    stage(c + 2, preA);
+                    if (c + 4 < nc) issue(c + 4, preA);
+                }
+                decide(c + 1);
             }
         }
+        if ((p.ablate & 8) && blockIdx.x == 0 && lane == 0)
+            printf("stager (even chunks): barrier-wait=%.0f stage=%.0f issue=%.0f cycles\n", 2.0 * t_bar / max(nc, 1), 2.0 * t_stage / max(nc, 1), 2.0 * t_issue / max(nc, 1));
     }
 }
 
@@ -1474,7 +1525,7 @@ __global__ void __launch_bounds__(64) gather_lin_kernel(GatherLinArgs p) {
     for (int k = lane + 64 * kGV; k < K; k += 64) m = fmaxf(m, row[direct ? k : labels[k]]);
     m = wave_max(m);
     if (!(m > -INFINITY)) m = 0.f;   // every label impossible in this frame: P = 0
-    double* prow = p.P + U[WF_U_P] + (int64_t)t * K;
+    double* prow = p.P + U[WF_U_P] + (int64_t)t * U[WF_U_PP];
     float* erow = p.E + U[WF_U_E] + (int64_t)t * K;
 #pragma unroll
     for (int i = 0; i < kGV; ++i) {
@@ -1855,7 +1906,8 @@ struct Plan {
     int over_deg_in = 0, over_deg_out = 0;
     int64_t n_E = 0, n_ab = 0, n_P = 0, n_rows = 0;
     bool lin = false;   // forward-backward by a linear-domain sweep (decided in make_plan)
-    int band_bw = 0, band_sn = 0, band_m = 1;   // banded form: widest band / most positions (band_bw < 0: some graph is not banded)
+    int band_bw = 0, band_sn = 0, band_m = 1;
+    bool band_we = true;   // every arc weight of every graph is 0   // banded form: widest band / most positions (band_bw < 0: some graph is not banded)
     int Tlong = 0;
 };
 
@@ -1873,7 +1925,7 @@ struct RegCfg {
     size_t lds = 0;
 };
 RegCfg lin_config(const Plan& P);
-struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; };
+struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; };
 BandSel band_config(const Plan& P);
 
 // dbl_exact: WF_DOUBLE_ACC (k2 use_double_scores=True): exp/log in fp64 too, log-semiring sweep only
@@ -1900,7 +1952,8 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         U[WF_U_ALPHA] = nab; U[WF_U_BETA] = nab; U[WF_U_E] = nE; U[WF_U_ROW0] = row0;
         U[WF_U_OFFS] = row0 + i;   // sum of (T+1) over the utterances before this one
         U[WF_U_P] = nP;
-        nP += (int64_t)T * I[WF_I_K];
+        U[WF_U_PP] = (I[WF_I_K] + 1) & ~1;
+        nP += (int64_t)T * U[WF_U_PP];
         U[WF_U_S] = I[WF_I_S]; U[WF_U_A] = I[WF_I_A]; U[WF_U_K] = I[WF_I_K]; U[WF_U_DIRECT] = I[WF_I_DIRECT];
         U[WF_U_MAXLABDEG] = I[WF_I_MAXLAB_DEG];
         U[WF_U_LAB_OFF] = I[WF_I_LAB_OFF]; U[WF_U_LAB_SRC] = I[WF_I_LAB_SRC]; U[WF_U_LAB_DST] = I[WF_I_LAB_DST];
@@ -1924,6 +1977,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         else if (P->band_bw >= 0) P->band_bw = std::max(P->band_bw, (int)I[WF_I_BAND_BW]);
         P->band_sn = std::max(P->band_sn, (int)I[WF_I_S] - 1);
         P->band_m = std::max(P->band_m, (int)I[WF_I_BAND_M]);
+        if (!I[WF_I_BAND_WE]) P->band_we = false;
         row0 += T;
     }
     P->n_E = nE; P->n_ab = nab; P->n_P = nP; P->n_rows = row0;
@@ -2107,23 +2161,23 @@ int lin_group(const RegCfg& c) { return c.threads <= 256 ? 8 : 4; }
 BandSel band_config(const Plan& P) {
     BandSel b;
     static const int no_band = env_int("WF_NO_BAND_SWEEP", 0);
-    if (no_band || P.band_bw < 0 || P.band_sn < 1) return b;
+    if (no_band || P.band_bw < 0 || P.band_sn < 1 || P.kmax >= kBandKP) return b;
     b.BW = P.band_bw <= 2 ? 2 : 4;
     b.R = std::max(b.BW, (P.band_sn + 63) / 64);
     if (b.R > WF_BAND_MAX_R) return b;
-    b.grp = (b.R * (b.BW + 1) <= 12) ? 8 : 4;
+    b.grp = kBandC;
     b.M = P.band_m <= 1 ? 1 : 2;
+    b.we = b.M == 1 && P.band_we;
     b.ok = true;
     return b;
 }
 
-template <int R, int BW, int MM>
+template <int R, int BW, int MM, bool WE>
 int launch_band_one(const SweepArgs& a, int B, hipStream_t st) {
-    using Cfg = BandCfg<R, BW>;
-    auto k = sweep_band_kernel<R, BW, MM>;
-    if (Cfg::LDS > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
-    hipLaunchKernelGGL(k, dim3(B * 2), dim3(Cfg::NT), Cfg::LDS, st, a);
+    auto k = sweep_band_kernel<R, BW, MM, WE>;
+    if (kBandLds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds));
+    hipLaunchKernelGGL(k, dim3(B * 2), dim3(128), kBandLds, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
@@ -2132,7 +2186,9 @@ int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st) {
     static const int prof = env_int("WF_SWEEP_PROFILE", 0);
     a.ablate = prof;
 #define WF_BAND_CASE(RR, WW)                                                                     \
-    if (b.BW == WW && b.R == RR) return b.M == 1 ? launch_band_one<RR, WW, 1>(a, B, st) : launch_band_one<RR, WW, 2>(a, B, st)
+    if (b.BW == WW && b.R == RR)                                                                  \
+        return b.we ? launch_band_one<RR, WW, 1, true>(a, B, st)                                   \
+                    : (b.M == 1 ? launch_band_one<RR, WW, 1, false>(a, B, st) : launch_band_one<RR, WW, 2, false>(a, B, st))
     WF_BAND_CASE(2, 2);
     WF_BAND_CASE(3, 2);
     WF_BAND_CASE(4, 2);
@@ -2337,15 +2393,25 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
             const size_t n = (size_t)num_seqs * Tmax * V;
             if (((uintptr_t)grad & 15) == 0 && !getenv("WF_ZERO_MEMSET")) {
                 const size_t n4 = n / 4;
-                // Size the grid so that the fill ends about when the sweeps do (~0.28 us per frame step,
-                // ~80 GB/s of streaming stores per workgroup): more workgroups than that only steal
+                // Size the grid so that the fill ends about when the sweeps do (~0.15 us per frame step,
+                // ~70 GB/s of streaming stores per workgroup): more workgroups than that only steal
                 // issue slots and memory-queue space from the latency-bound sweep workgroups
-                // (measured on cfg3: 32-64 blocks -> sweep 140 us; 1024 blocks -> 172 us).
-                int want = (int)((double)n * 4.0 / (std::max(P.Tlong, 1) * 0.28e-6) / 80e9) + 1;
+                // (measured on cfg3: 64 blocks -> fill 73 us, sweep 80 us; 256 blocks -> 62 / 98; 1024 -> 74 / 114).
+                int want = (int)((double)n * 4.0 / (std::max(P.Tlong, 1) * 0.15e-6) / 70e9) + 1;
                 want = std::max(32, std::min(want, 2048));
                 if (getenv("WF_ZERO_BLOCKS")) want = atoi(getenv("WF_ZERO_BLOCKS"));
                 const int blocks = (int)std::min<size_t>((n4 + 255) / 256, (size_t)want);
-                hipLaunchKernelGGL(zero_flat_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, side->stream,
+                // The fill blocks ask for (and never touch) more than half of a CU's LDS: the latency-bound sweep
+                // workgroups do the same, so no fill block lands on a sweep workgroup's CU, where its four waves
+                // would compete with the chain wave for issue slots (measured: the co-resident sweep workgroups
+                // ran 1.6-3.8x longer and set the kernel's duration).
+                constexpr int kFillLds = 84 * 1024;
+                static bool fill_attr = false;
+                if (!fill_attr) {
+                    HIP_TRY(hipFuncSetAttribute((const void*)zero_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFillLds));
+                    fill_attr = true;
+                }
+                hipLaunchKernelGGL(zero_flat_kernel, dim3(std::max(blocks, 1)), dim3(256), kFillLds, side->stream,
                                    (float4*)grad, n4, grad + n4 * 4, (int)(n - n4 * 4));
                 HIP_TRY(hipGetLastError());
             } else {
