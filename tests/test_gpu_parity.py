@@ -240,3 +240,130 @@ def test_full_size_mmictc_denominator_properties():
         T = int(c["segs"][b, 2])
         np.testing.assert_allclose(grad[b, :T].sum(-1), -1.0, atol=2e-3)
         assert np.all(grad[b, T:] == 0)
+
+
+# ---- every sweep implementation behind wf_fb_logsum, on the same inputs ----------------------------
+# default: banded wave sweep (numerators) / linear-domain LDS sweep; the environment hooks below force
+# the other kernels and the check -> fallback path, so that each one is held to the same tolerances.
+
+SWEEP_PATHS = {
+    "default": {},
+    "lin_lds": {"WF_NO_BAND_SWEEP": "1"},
+    "log_generic": {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "1"},
+    "band_then_fallback": {"WF_FORCE_FALLBACK": "1"},
+    "lin_then_fallback": {"WF_NO_BAND_SWEEP": "1", "WF_FORCE_FALLBACK": "1"},
+}
+
+
+def fused_logsum(fsa, lp, segs, gscale=-1.0):
+    """wf_fb_logsum with grad != NULL (loss + gradient in one call: the path bench.py times)."""
+    import ctypes as C
+    from waterfall_amd import _lib
+    lib = _lib.lib()
+    x = torch.from_numpy(np.ascontiguousarray(lp)).to(DEV)
+    N, T, V = x.shape
+    segs = np.ascontiguousarray(segs, dtype=np.int32)
+    B = segs.shape[0]
+    gh, gd = fsa.blob_host(), fsa.blob_dev(torch.device(DEV))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    npp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+    n = C.c_size_t(0)
+    _lib.check(lib.wf_fb_workspace_bytes(npp(gh), npp(fsa.utt2fsa), npp(segs), B, V, 0, 1, C.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=DEV)
+    tot = torch.empty(B, dtype=torch.float32, device=DEV)
+    grad = torch.full_like(x, 7.0)   # every element must be overwritten
+    gs = torch.full((B,), gscale, dtype=torch.float32, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
+    _lib.check(lib.wf_fb_logsum(npp(gh), p(gd), npp(fsa.utt2fsa), p(x), x.stride(0), x.stride(1), N, T, V, npp(segs), B,
+                                0.0, 0, p(gs), p(tot), p(grad), p(ws), n.value, st))
+    torch.cuda.synchronize()
+    return tot.cpu().numpy(), grad.cpu().numpy()
+
+
+def _with_env(env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+SWEEP_CASES = [
+    # topo, den, L, T, P  -> banded instantiation it reaches by default
+    ("ctc", False, 7, 50, 9),          # <2,2>
+    ("ctc", False, 45, 130, 30),       # <2,2>, S = 92
+    ("ctc", False, 80, 203, 40),       # <3,2>, T not a multiple of the chunk
+    ("ctc", False, 100, 230, 40),      # <4,2>
+    ("2state", False, 30, 100, 12),    # <2,2>
+    ("3state-skip-2", False, 20, 90, 9),   # band 3 -> <4,4>
+    ("mmictc", False, 20, 90, 9),      # band 4, two arcs per cell -> <4,4,2>
+    ("2state_sil3", False, 10, 70, 9),  # three parallel arcs: not banded-eligible -> linear LDS sweep
+    ("2state", True, 5, 60, 12),       # denominator: hub state, not banded -> linear LDS sweep with a cooperative state
+    ("mmictc", True, 5, 33, 7),
+    ("ctc", False, 3, 1, 5),           # single frame (infeasible for 3 labels)
+    ("ctc", False, 2, 5, 5),
+]
+
+
+@pytest.mark.parametrize("path", sorted(SWEEP_PATHS))
+@pytest.mark.parametrize("topo,den,L,T,P", SWEEP_CASES)
+def test_sweep_paths_fused_and_autograd(path, topo, den, L, T, P):
+    c = util.random_case(300 + L + T, topo, B=5, T=T, L=L, P=P, den=den, ragged=T > 10)
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    ok = np.isfinite(want)
+
+    def run():
+        tot, grad = fused_logsum(c["fsa"], c["lp"], c["segs"])
+        loss, agrad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
+        return tot, grad, loss, agrad
+    tot, grad, loss, agrad = _with_env(SWEEP_PATHS[path], run)
+    for got_loss, got_grad in ((-tot, grad), (loss, agrad)):
+        assert np.array_equal(np.isfinite(got_loss), ok)
+        np.testing.assert_allclose(got_loss[ok], want[ok], rtol=TOT_RTOL, atol=TOT_ATOL)
+        np.testing.assert_allclose(got_grad, wgrad, atol=GRAD_ATOL)
+        assert not np.isnan(got_grad).any()
+
+
+@pytest.mark.parametrize("path", sorted(SWEEP_PATHS))
+def test_sweep_paths_weighted_arcs(path):
+    # arc weights != 0 (LM-like scores): the banded sweep's weighted instantiation and the others
+    c = util.random_case(77, "ctc", B=4, T=60, L=9, P=8)
+    rng = np.random.default_rng(5)
+    graphs = []
+    for g in c["ographs"]:
+        g = dict(g)
+        g["score"] = (rng.standard_normal(g["score"].shape) * 0.7).astype(np.float32)
+        graphs.append(g)
+    fsa = util.graphs_to_fsa(graphs)
+    want, wgrad = o.graphloss(graphs, c["lp"], c["segs"], None, "none")
+    tot, grad = _with_env(SWEEP_PATHS[path], lambda: fused_logsum(fsa, c["lp"], c["segs"]))
+    np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+
+
+def test_linear_sweep_underflow_is_caught_by_the_row_check():
+    # A forced alignment through labels ~900 nats below each frame's best label in the first half of
+    # the utterance: the probability-domain sweeps lose those states (fp64 underflow after rescaling to
+    # the row maximum is impossible here, but exp(lp - c_t) of the needed labels is 0), the row identity
+    # fails, and the log-semiring fallback must deliver the exact result.
+    topo, tokens = wf.build_topology("ctc", util.ctc_phones(6))
+    fsa = wf.compile_ctc_k2_graphs(topo, [[1, 2, 3], [2, 2]])
+    T, V = 40, len(tokens)
+    lp = np.full((2, T, V), -900.0, dtype=np.float32)
+    lp[:, :, 4] = 0.0          # the model insists on a label that is not in either transcript
+    lp[1, :, :] = np.log(1.0 / V)   # the second utterance is ordinary
+    segs = np.array([[0, 0, T], [1, 0, T]], dtype=np.int32)
+    want, wgrad = o.graphloss(fsa.as_oracle_graphs(), lp, segs, None, "none")
+    assert np.isfinite(want).all() and want[0] > 30000
+    tot, grad = fused_logsum(fsa, lp, segs)
+    np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+    loss, agrad = run_hip(fsa, lp, segs, "none")
+    np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(agrad, wgrad, atol=GRAD_ATOL)

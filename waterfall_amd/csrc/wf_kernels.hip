@@ -1419,6 +1419,7 @@ struct CheckArgs {
     const double* ctot2;
     int32_t* flag;
     int grp, lag;   // frames per rescale group of the sweep that wrote the rows; see lin_shift_index
+    int force;      // test hook (WF_FORCE_FALLBACK): flag every utterance
 };
 
 // log2 of a non-negative double as (integer part exactly, fraction in fp32): log2(0) = -inf
@@ -1433,6 +1434,7 @@ __global__ void __launch_bounds__(64) check_kernel(CheckArgs p) {
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int T = (int)U[WF_U_T];
     if (t > T) return;
+    if (p.force) { if (t == 0 && lane == 0) p.flag[u] = 1; return; }
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
     const int S = (int)U[WF_U_S];
     const double tot2 = p.tot2[u];
@@ -1764,31 +1766,35 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     }
 }
 
-// One wavefront per gradient row for small compact graphs (numerators): S, A, K <= 64 * kPS.
-// Everything the row needs is fetched in two batches of independent loads (header, then alpha /
-// beta / emissions / arc descriptors together), so a wave pays ~3 memory latencies in all and the
-// 16 000 rows of a batch run as 16 000 independent waves.  Rows are pre-zeroed (skip_zero).
-constexpr int kPS = 8;
+// Gradient rows of small compact graphs (numerators: S, K <= 64 * PSS, A <= 128 * PSS), rows pre-zeroed
+// (skip_zero).  One wavefront per kPostFR consecutive frames of one utterance: the arc descriptors are
+// frame-independent and stay in registers, the next frame's alpha / beta / emission values are loaded
+// while the current frame is reduced, and a column shared by many arcs (the blank of a CTC numerator
+// sits on ~40% of the arcs) is summed by the whole wave (fixed tree: bit-stable) instead of one lane.
+constexpr int kPostFR = 4;
+constexpr int kPostHeavy = 16;   // arcs per column from which the wave sums the column cooperatively
 
+template <int PSS>
 __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
+    constexpr int PSA = 2 * PSS;
     extern __shared__ __align__(16) unsigned char smem[];
     float* la = (float*)smem;
     float* lb = la + p.smax;
     float* le = lb + p.smax;
     float* lpost = le + p.ecap;
     const int lane = threadIdx.x;
-    const int f = blockIdx.x, q = blockIdx.y;
+    const int f0 = blockIdx.x * kPostFR, q = blockIdx.y;
     const int u = p.seq2utt[q];
     if (u < 0) return;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
-    const int t = f - start;
     const double tot = p.totd[u];
-    if (t < 0 || t >= T || tot == (double)-INFINITY) return;
+    const int t0 = max(f0 - start, 0), t1 = min(f0 + kPostFR - start, T);
+    if (t0 >= t1 || tot == (double)-INFINITY) return;
     const int S = (int)U[WF_U_S], A = (int)U[WF_U_A], K = (int)U[WF_U_K];
-    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
-    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
-    const float* erow = p.E + U[WF_U_E] + (int64_t)t * K;
+    const double* abase = p.alpha + U[WF_U_ALPHA];
+    const double* bbase = p.beta + U[WF_U_BETA];
+    const float* ebase = p.E + U[WF_U_E];
     const bool lin = !p.flag[u];   // flagged: the fallback left natural-log fp64 rows
     const int32_t* loff = p.blob + U[WF_U_LAB_OFF];
     const int32_t* lsrc = p.blob + U[WF_U_LAB_SRC];
@@ -1797,61 +1803,106 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     const float* lw = (const float*)(p.blob + U[WF_U_LAB_W]);
     const int32_t* labels = p.blob + U[WF_U_LABELS];
     const float gs = p.gscale ? p.gscale[u] : 1.f;
-    float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
+    // per-utterance constants of the linear-sweep row format
+    const double ctot2 = lin ? p.ctot2[u] : 0.0, tot2 = lin ? p.tot2[u] : 0.0;
+    const double* aoffs = p.aoff + U[WF_U_OFFS];
+    const double* boffs = p.boff + U[WF_U_OFFS];
+    const double* cmax = p.cmax + U[WF_U_ROW0];
 
-    // ---- batch 2: all independent loads (indices clamped so that no load is conditional)
-    double av[kPS], bv[kPS];
-    float ev[kPS];
-    int asrc[kPS], adst[kPS], acol[kPS];
-    float aw[kPS];
+    // ---- frame-independent: this lane's arcs and columns (indices clamped so that no load is conditional)
+    int asrc[PSA], adst[PSA], acol[PSA];
+    float aw[PSA];
 #pragma unroll
-    for (int i = 0; i < kPS; ++i) {
-        const int s = min(lane + i * 64, S - 1);
-        av[i] = arow[s];
-        bv[i] = brow[s];
-        ev[i] = erow[min(lane + i * 64, K - 1)];
+    for (int i = 0; i < PSA; ++i) {
         const int a = min(lane + i * 64, A - 1);
-        asrc[i] = lsrc[a]; adst[i] = ldst[a]; acol[i] = lcol[a]; aw[i] = lw[a];
+        asrc[i] = lsrc[a]; adst[i] = ldst[a]; acol[i] = lcol[a]; aw[i] = lw[a] * kLog2e;
     }
-    double a_ref, b_ref;
-    float xs;
-    if (lin) {
-        a_ref = lin_post_const(p, U, u, t, T) + (double)kLinBias;
-        b_ref = -(double)kLinBias;
-        xs = 1.f;
-    } else {
-        double mx = (double)-INFINITY;
+    int k0[PSS], k1[PSS], kend[PSS], klab[PSS];
+    unsigned long long heavy[PSS];   // wave mask of the columns of slot i that are summed cooperatively
 #pragma unroll
-        for (int i = 0; i < kPS; ++i) mx = fmax(mx, av[i]);   // clamped duplicates do not change the maximum
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, shfl_xor(mx, o));
-        a_ref = mx;
-        b_ref = tot - mx;
-        xs = kLog2e;
+    for (int i = 0; i < PSS; ++i) {
+        const int k = min(lane + i * 64, K - 1);
+        k0[i] = loff[k]; k1[i] = kend[i] = loff[k + 1]; klab[i] = labels[k];
+        const bool mine = lane + i * 64 < K;
+        heavy[i] = __ballot(mine && k1[i] - k0[i] > kPostHeavy);
+        if (!mine || k1[i] - k0[i] > kPostHeavy) k1[i] = k0[i];   // nothing left for the per-lane loop
     }
+
+    // ---- row prefetch registers (frame t): alpha_t, beta_{t+1}, emissions, offsets
+    double av[PSS], bv[PSS], c_t, ga, gb;
+    float ev[PSS];
+    auto fetch = [&](const int t) __attribute__((always_inline)) {
+        const double* arow = abase + (int64_t)t * S;
+        const double* brow = bbase + (int64_t)(t + 1) * S;
+        const float* erow = ebase + (int64_t)t * K;
 #pragma unroll
-    for (int i = 0; i < kPS; ++i) {
-        const int s = lane + i * 64;
-        if (s < S) {
-            la[s] = lin ? lin_log2f(av[i], a_ref) : (float)(av[i] - a_ref);
-            lb[s] = lin ? lin_log2f(bv[i], b_ref) : (float)(bv[i] - b_ref);
+        for (int i = 0; i < PSS; ++i) {
+            const int s = min(lane + i * 64, S - 1);
+            av[i] = arow[s];
+            bv[i] = brow[s];
+            ev[i] = erow[min(lane + i * 64, K - 1)];
         }
-        if (s < K) le[s] = ev[i];
-    }
-    __syncthreads();
+        c_t = lin ? cmax[t] : 0.0;
+        ga = aoffs[lin ? lin_shift_index(t - 1, p.lin, p.lag) : 0];
+        gb = boffs[lin ? lin_shift_index(T - 2 - t, p.lin, p.lag) : 0];
+    };
+    fetch(t0);
+    for (int t = t0; t < t1; ++t) {
+        // ---- this frame's values -> LDS (log2 domain, both vectors centred)
+        double a_ref, b_ref;
+        float xs;
+        if (lin) {
+            a_ref = ctot2 - c_t * kLog2eD - tot2 - ga - gb + (double)kLinBias;
+            b_ref = -(double)kLinBias;
+            xs = 1.f;
+        } else {
+            double mx = (double)-INFINITY;
 #pragma unroll
-    for (int i = 0; i < kPS; ++i) {
-        const int a = lane + i * 64;
-        if (a < A) lpost[a] = __builtin_amdgcn_exp2f((la[asrc[i]] + lb[adst[i]]) * xs + (aw[i] + le[acol[i]]) * kLog2e);
-    }
-    __syncthreads();
-    // per-column sums in arc order (bit-stable)
-    for (int k = lane; k < K; k += 64) {
-        const int a0 = loff[k], a1 = loff[k + 1];
-        const int lab = labels[k];
-        float acc = 0.f;
-        for (int a = a0; a < a1; ++a) acc += lpost[a];
-        grow[lab] = gs * acc;
+            for (int i = 0; i < PSS; ++i) mx = fmax(mx, av[i]);   // clamped duplicates do not change the maximum
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, shfl_xor(mx, o));
+            a_ref = mx;
+            b_ref = tot - mx;
+            xs = kLog2e;
+        }
+#pragma unroll
+        for (int i = 0; i < PSS; ++i) {
+            const int s = lane + i * 64;
+            if (s < S) {
+                la[s] = lin ? lin_log2f(av[i], a_ref) : (float)(av[i] - a_ref) * xs;
+                lb[s] = lin ? lin_log2f(bv[i], b_ref) : (float)(bv[i] - b_ref) * xs;
+            }
+            if (s < K) le[s] = ev[i] * kLog2e;
+        }
+        if (t + 1 < t1) fetch(t + 1);   // next frame's loads fly while this frame is reduced
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PSA; ++i) {
+            const int a = lane + i * 64;
+            if (a < A) lpost[a] = __builtin_amdgcn_exp2f(la[asrc[i]] + lb[adst[i]] + (aw[i] + le[acol[i]]));
+        }
+        __syncthreads();
+        float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)(start + t) * p.strideT;
+        // per-column sums in arc order (bit-stable)
+#pragma unroll
+        for (int i = 0; i < PSS; ++i) {
+            if (lane + i * 64 < K && !((heavy[i] >> lane) & 1)) {
+                float acc = 0.f;
+                for (int a = k0[i]; a < k1[i]; ++a) acc += lpost[a];
+                grow[klab[i]] = gs * acc;
+            }
+            unsigned long long hm = heavy[i];
+            while (hm) {   // wave-uniform
+                const int hl = __builtin_ctzll(hm);
+                hm &= hm - 1;
+                const int a0 = __shfl(k0[i], hl, 64), a1 = __shfl(kend[i], hl, 64);
+                float acc = 0.f;
+                for (int a = a0 + lane; a < a1; a += 64) acc += lpost[a];
+                acc = wave_sum(acc);
+                if (lane == hl) grow[klab[i]] = gs * acc;
+            }
+        }
+        __syncthreads();   // la / lb / le / lpost are rewritten by the next frame
     }
 }
 
@@ -2120,7 +2171,7 @@ int env_int(const char* name, int dflt) {
 
 RegCfg reg_config(const Plan& P, bool both_dirs) {
     RegCfg c;
-    static const int no_reg = env_int("WF_NO_REG_SWEEP", 0);
+    const int no_reg = env_int("WF_NO_REG_SWEEP", 0);   // test hook, read per call
     if (no_reg) return c;
     if (!P.arcs_lds_ok || P.smax > kMaxThreads || !P.reg_ok_in || (both_dirs && !P.reg_ok_out)) return c;
     // four lanes per state; R states per quad once 4*S exceeds the workgroup
@@ -2141,7 +2192,7 @@ RegCfg reg_config(const Plan& P, bool both_dirs) {
 // direction has <= WF_REG_DEG arcs; the exceptional state's arcs fit HD <= 2 per lane
 RegCfg lin_config(const Plan& P) {
     RegCfg c;
-    static const int no_lin = env_int("WF_NO_LIN_SWEEP", 0);
+    const int no_lin = env_int("WF_NO_LIN_SWEEP", 0);   // test hook, read per call
     if (no_lin) return c;
     if (P.smax > kMaxThreads || !P.reg_ok_in || !P.reg_ok_out) return c;
     c.threads = std::max(64, (int)align_up(P.smax, 64));
@@ -2160,7 +2211,7 @@ int lin_group(const RegCfg& c) { return c.threads <= 256 ? 8 : 4; }
 // banded wave sweep: every graph of the call is banded and fits one wavefront; picks the instantiation
 BandSel band_config(const Plan& P) {
     BandSel b;
-    static const int no_band = env_int("WF_NO_BAND_SWEEP", 0);
+    const int no_band = env_int("WF_NO_BAND_SWEEP", 0);   // test hook, read per call
     if (no_band || P.band_bw < 0 || P.band_sn < 1 || P.kmax >= kBandKP) return b;
     b.BW = P.band_bw <= 2 ? 2 : 4;
     b.R = std::max(b.BW, (P.band_sn + 63) / 64);
@@ -2270,8 +2321,18 @@ extern "C" int wf_viterbi_workspace_bytes(const void* graph_host, const int32_t*
 namespace {
 // copies the per-call tables into the workspace and launches the gather when needed
 int upload_tables(const Plan& P, unsigned char* ws, const int32_t* seq2utt, int num_seqs, hipStream_t st) {
-    HIP_TRY(hipMemcpyAsync(ws + P.off_utt, P.utt.data(), sizeof(int64_t) * P.utt.size(), hipMemcpyHostToDevice, st));
-    if (seq2utt) HIP_TRY(hipMemcpyAsync(ws + P.off_seq2utt, seq2utt, sizeof(int32_t) * num_seqs, hipMemcpyHostToDevice, st));
+    // one host-to-device copy for both tables (each copy costs ~4 us of stream time): the workspace regions
+    // are adjacent (off_utt, then off_seq2utt), so stage them in one buffer with the same layout
+    const size_t utt_bytes = sizeof(int64_t) * P.utt.size();
+    if (!seq2utt) {
+        HIP_TRY(hipMemcpyAsync(ws + P.off_utt, P.utt.data(), utt_bytes, hipMemcpyHostToDevice, st));
+        return WF_OK;
+    }
+    const size_t span = (P.off_seq2utt - P.off_utt) + sizeof(int32_t) * (size_t)num_seqs;
+    std::vector<unsigned char> stage(span, 0);
+    memcpy(stage.data(), P.utt.data(), utt_bytes);
+    memcpy(stage.data() + (P.off_seq2utt - P.off_utt), seq2utt, sizeof(int32_t) * (size_t)num_seqs);
+    HIP_TRY(hipMemcpyAsync(ws + P.off_utt, stage.data(), span, hipMemcpyHostToDevice, st));
     return WF_OK;
 }
 
@@ -2327,11 +2388,15 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     q.acap = (P.maxlabdeg > 8 && P.amax <= 8192) ? (int)align_up(P.amax, 4) : 0;
     q.skip_zero = skip_zero ? 1 : 0;
     size_t lds = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
-    if (P.lin && skip_zero && !getenv("WF_NO_POST_SMALL") && P.all_compact && P.amax >= 1 && P.amax <= 64 * kPS && P.smax <= 64 * kPS &&
-        P.kmax_compact <= 64 * kPS && q.ecap > 0) {
+    if (P.lin && skip_zero && !getenv("WF_NO_POST_SMALL") && P.all_compact && P.amax >= 1 && P.amax <= 128 * 8 && P.smax <= 64 * 8 &&
+        P.kmax_compact <= 64 * 8 && q.ecap > 0) {
         q.acap = (int)align_up(P.amax, 4);
         size_t lds2 = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
-        hipLaunchKernelGGL(post_small_kernel, dim3(Tmax, num_seqs), dim3(64), lds2, st, q);
+        const int need = std::max(std::max((P.smax + 63) / 64, (P.kmax_compact + 63) / 64), (P.amax + 127) / 128);
+        const dim3 grid((Tmax + kPostFR - 1) / kPostFR, num_seqs);
+        if (need <= 2) hipLaunchKernelGGL(post_small_kernel<2>, grid, dim3(64), lds2, st, q);
+        else if (need <= 4) hipLaunchKernelGGL(post_small_kernel<4>, grid, dim3(64), lds2, st, q);
+        else hipLaunchKernelGGL(post_small_kernel<8>, grid, dim3(64), lds2, st, q);
         HIP_TRY(hipGetLastError());
         return WF_OK;
     }
@@ -2444,7 +2509,8 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
         CheckArgs k{a.blob, a.utt, (const double*)a.alpha, (const double*)a.beta, a.aoff, a.boff, a.tot2, a.ctot2,
-                    (int32_t*)(ws + P.off_flag), bs.ok ? bs.grp : lin_group(lin_config(P)), bs.ok ? 0 : 1};
+                    (int32_t*)(ws + P.off_flag), bs.ok ? bs.grp : lin_group(lin_config(P)), bs.ok ? 0 : 1,
+                    env_int("WF_FORCE_FALLBACK", 0)};
         hipLaunchKernelGGL(check_kernel, dim3(P.Tlong + 1, B), dim3(64), 0, st, k);
         HIP_TRY(hipGetLastError());
         SweepCfg fc = sweep_config_minimal(P, ab);
