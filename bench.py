@@ -6,8 +6,9 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic log-probs already resident in
-HBM: emission gather -> concurrent alpha/beta sweeps -> posterior/gradient rows (loss + gradient
-w.r.t. log_probs, reduction 'sum'), called through the C ABI (wf_fb_logsum).  The headline workload
+HBM: emission gather (probabilities) -> concurrent alpha/beta sweeps (with the gradient zero-fill
+beside them on a side stream) -> row check -> posterior/gradient rows (loss + gradient w.r.t.
+log_probs, reduction 'sum'), called through the C ABI (wf_fb_logsum).  The headline workload
 is BASELINE.json configs[2] (the configuration the metric is quoted on: B=32, T=500, V=5k, CTC
 numerator graphs, "cfg3" in BASELINE.md); with N GPUs every rank processes its own B=32 batch
 (weak scaling, utterances are independent) and the step ends with ONE RCCL all-reduce of the fused
@@ -34,6 +35,19 @@ import waterfall_amd as wf  # noqa: E402
 from waterfall_amd import _lib  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+KERNEL_NAMES = {"gather": "gather_lin_kernel", "sweep": "sweep_band_kernel", "post": "post_small_kernel",
+                "zero": "zero_flat_kernel", "check": "check_kernel"}
+PMC_FILE = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def pmc_traffic(kernel, is_default_workload):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read), or None when there is no
+    measurement for this workload."""
+    if not is_default_workload or not os.path.exists(PMC_FILE):
+        return None
+    k = json.load(open(PMC_FILE))["kernels"].get(KERNEL_NAMES.get(kernel, ""))
+    return k["hbm_bytes_per_launch_fetch_doubled"] if k else None
 
 WORKLOADS = {
     # name: (topology, P, L, kind) -- BASELINE.md section 3
@@ -259,7 +273,7 @@ def main():
         "metric": "DWFST loss+grad utterance-frames/sec",
         "value": value, "unit": "utterance-frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (alpha/beta accumulated in f64)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}, B={args.batch} per GPU, "
                                f"T={args.frames}{' ragged' if args.ragged else ''}, loss+grad, reduction=sum, exact (no output_beam pruning)",
                    "batch_per_gpu": args.batch, "frames": args.frames, "V": wl.V,
@@ -272,11 +286,16 @@ def main():
         kb = wl.kernel_bytes(lin=kt["check"] >= 0)
         dom = max(kt, key=lambda k: kt[k])
         ach = kb[dom] / (kt[dom] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        default_wl = (args.workload == "cfg3_ctc_bpe5k_num" and args.batch == 32 and args.frames == 500
+                      and not args.ragged)
+        out["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom) if kt["check"] >= 0 else dom + "_kernel",
+                           "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, default_wl),
                            "avg_launch_ms": kt[dom], "algorithmic_bytes_per_launch": kb[dom],
-                           "note": "the alpha/beta sweep is dependency-latency bound (T sequential frame steps), "
-                                   "not bandwidth bound: us_per_frame_step below is its real figure of merit"}
+                           "note": "dominant kernel by duration. The alpha/beta sweep is dependency-latency bound (T "
+                                   "sequential frame steps; kernels.sweep.us_per_frame_step is its figure of merit); the "
+                                   "only bandwidth-bound kernel is the gradient zero-fill, which runs beside the sweep on "
+                                   "a side stream (kernels.zero). traffic: profiles/r01c_pmc_traffic.json"}
         out["kernels"] = {k: {"avg_ms": kt[k], "algorithmic_bytes": kb[k],
                               "GBps": kb[k] / (kt[k] * 1e-3) / 1e9 if kt[k] > 0 else None} for k in kt}
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames

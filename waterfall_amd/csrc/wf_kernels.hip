@@ -1,26 +1,27 @@
 // HIP kernels (gfx950 / CDNA4) and C-ABI compute entry points of libwfdwfst.so.
 //
-// What runs on the GPU for one wf_fb_logsum() call (reference: waterfall/graph.py:61-66 and its
-// autograd backward, i.e. k2.intersect_dense + get_tot_scores + their backward passes):
+// What runs on the GPU for one wf_fb_logsum() call with a gradient (reference: waterfall/graph.py:61-66
+// and its autograd backward, i.e. k2.intersect_dense + get_tot_scores + their backward passes); see
+// DESIGN.md section 4 for the measurements behind each choice:
 //
-//   1. gather_kernel    E[i,t,k] = log_probs[b, start+t, label_k]  for graphs that use few labels
-//                       (numerators); graphs that use most labels (denominators) read log_probs
-//                       rows directly.  Fully parallel, HBM/L2 bound.
-//   2. sweep_kernel     one workgroup per (utterance, direction).  Frame-synchronous recursion with
-//                       alpha (or beta) double-buffered in LDS, the CSR arc arrays staged in LDS
-//                       when they fit, emission rows prefetched a chunk of frames ahead through
-//                       registers into an LDS ring, lane-per-state log-sum-exp for ordinary states
-//                       and a wavefront-shuffle + LDS block reduction for high fan-in states.
-//                       Forward and backward sweeps are independent and run concurrently; every
-//                       alpha_t / beta_t row is streamed to the workspace.  Latency bound (T
-//                       dependent steps), no lattice is ever materialised.
-//   3. post_kernel      one workgroup per (sequence, frame): arc posteriors
-//                       exp(alpha_t[src] + x + beta_{t+1}[dst] - tot) reduced per label in a fixed
-//                       order (no float atomics => bit-stable), then the whole gradient row is
-//                       written (zeros + K values for numerators).  HBM-write bound.
+//   1. gather_lin_kernel   P[i,t,k] = exp(log_probs[b, start+t, label_k] - c_t) in fp64 (c_t = the row's
+//                          maximum) and the raw values E[i,t,k].  Fully parallel.
+//   2. sweep_band_kernel   (graphs with a banded state order: every topo o transcript numerator) or
+//      sweep_lin_kernel    (other graphs of <= 1024 states): the forward and the backward recursion in
+//                          the PROBABILITY domain (fp64, rescaled by powers of two), one workgroup per
+//                          (utterance, direction), every alpha_t / beta_t row streamed to the workspace.
+//                          Latency bound (T dependent steps); no lattice is ever materialised.
+//      zero_flat_kernel    beside them on a side stream: zero-fill of the gradient box (HBM-write bound).
+//   3. check_kernel        sum_s alpha_t[s] * beta_t[s] = tot on every row, else the utterance is flagged
+//   4. sweep_kernel        (log semiring, fp64 accumulators) re-runs flagged utterances: exits at once otherwise
+//   5. post_small_kernel / post_kernel   arc posteriors reduced per label in a fixed order (no float
+//                          atomics => bit-stable), K values scattered into the zeroed gradient row.
 //
-// wf_viterbi(): sweep_kernel in the tropical semiring storing one back-pointer per lattice state,
-// then backtrace_kernel (one lane per utterance).
+// Graphs too large for 2./3. and WF_DOUBLE_ACC take sweep_kernel directly (frame-synchronous log-semiring
+// recursion with alpha double-buffered in LDS, CSR arcs staged in LDS when they fit, emission rows
+// prefetched through an LDS ring, block reduction for high fan-in states).
+// Forward-only calls and wf_viterbi(): sweep_quad_kernel / sweep_kernel in the log or tropical semiring
+// (one back-pointer per lattice state), then backtrace_kernel (one lane per utterance).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -1107,7 +1108,7 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
 // leave the chain wave as plain stores (never waited for).  The backward sweep is the same code on
 // the reversed order.  Rescaling (once per chunk, decided by the stager from the exponents of the
 // previous chunk's last row) and the row check / fallback are as for sweep_lin_kernel.
-// Measured (cfg3, MI355X): ~NNN cycles per frame step against ~440 for sweep_lin_kernel.
+// Measured (cfg3, MI355X): 190 cycles per frame step against 440 for sweep_lin_kernel.
 // ------------------------------------------------------------------------------------------
 constexpr int kBandKP = 192;   // row pitch of the staged emission rows; a banded graph uses < kBandKP label columns
 constexpr int kBandC = 16;     // frames per chunk
