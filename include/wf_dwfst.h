@@ -57,6 +57,9 @@ extern "C" {
 #define WF_TROPICAL 2u    /* wf_tot_scores only: max instead of log-sum-exp                       */
 #define WF_KEEP_AB 4u     /* wf_fb_logsum with grad == NULL: still run both sweeps and leave alpha/
                              beta in the workspace so that wf_fb_backward() can follow later       */
+#define WF_PRUNED 8u      /* wf_fb_logsum is called with 0 < output_beam < inf: pass it to
+                             wf_fb_workspace_bytes, wf_fb_logsum and wf_fb_backward alike (the tropical
+                             first pass and its thresholds need workspace)                          */
 
 typedef struct {
     int32_t num_fsas;                 /* G                                                     */
@@ -95,8 +98,11 @@ int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const 
 
 /* ---- log-semiring forward-backward: total scores and gradient (graph.py:61-66 + autograd) ---
  * log_probs: device fp32, element (b,t,v) at b*strideB + t*strideT + v.
- * output_beam: <= 0 or +inf disables pruning (exact sum over all lattice arcs); otherwise arcs
- *   whose best path is more than output_beam below the best path are dropped.
+ * output_beam: <= 0 or +inf disables pruning (exact sum over all lattice arcs); otherwise (with
+ *   WF_PRUNED in flags) a lattice arc (t, a) is kept iff alpha^_t[src] + x + beta^_{t+1}[dst] >=
+ *   best - output_beam in the tropical semiring (k2.intersect_dense's output_beam, graph.py:61-62;
+ *   k2 is not available to pin this arithmetic against: SURVEY 8(0) / 8(c)), at the cost of a
+ *   tropical forward-backward pass in front of the log-semiring one.
  * grad_scale: DEVICE fp32 [B] or NULL(=1): grad[b,t,v] = grad_scale[i] * sum of arc posteriors,
  *   i.e. -1 for d(-tot)/d log_probs, -1/(B*target_len) for reduction 'mean' (graph.py:74-76).
  * tot: device fp32 [B].  grad: device fp32, same strides as log_probs, every element of the

@@ -367,3 +367,63 @@ def test_linear_sweep_underflow_is_caught_by_the_row_check():
     loss, agrad = run_hip(fsa, lp, segs, "none")
     np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(agrad, wgrad, atol=GRAD_ATOL)
+
+
+# ---- output_beam pruning (k2.intersect_dense, graph.py:61-62; arithmetic parity-unpinned: SURVEY 8(0)) ----
+
+@pytest.mark.parametrize("beam", [0.5, 2.0, 5.0, 10.0])
+@pytest.mark.parametrize("topo,den", [("ctc", False), ("2state", False), ("mmictc", True), ("3state-skip", True)])
+def test_output_beam_pruning_matches_oracle(beam, topo, den):
+    c = util.random_case(500 + int(beam * 10), topo, B=4, T=40, L=6, P=7, den=den)
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], beam, "none")
+    wf.set_output_beam_mode("pruned")
+    try:
+        x = torch.from_numpy(c["lp"]).to(DEV).requires_grad_(True)
+        dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
+        loss = wf.graphloss(c["fsa"], dense, output_beam=beam, reduction="none")
+        loss.sum().backward()
+    finally:
+        wf.set_output_beam_mode("exact")
+    # the tropical pass runs in fp32 here and in fp64 in the oracle: an arc within rounding of the
+    # threshold may fall on either side; it carries e^-beam of the best path's mass at most
+    slack = 3e-3 if beam < 1 else 1e-3
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), want, rtol=TOT_RTOL, atol=slack)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), wgrad, atol=max(GRAD_ATOL, slack))
+    exact, _ = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    if beam <= 2.0:
+        assert np.all(want >= exact - 1e-9) and np.any(want > exact + 1e-3)   # pruning really removed mass
+
+
+def test_output_beam_10_is_within_tolerance_of_exact():
+    # the drop-in's default ("exact" mode) against what the reference's default beam would keep
+    c = util.random_case(61, "2state", B=6, T=120, L=14, P=12)
+    pruned, pgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], 10.0, "none")
+    loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
+    np.testing.assert_allclose(loss, pruned, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, pgrad, atol=GRAD_ATOL)
+
+
+def test_output_beam_fused_entry_point_needs_the_flag():
+    import ctypes as C
+    from waterfall_amd import _lib
+    c = util.random_case(62, "ctc", B=2, T=20, L=3, P=5)
+    lib = _lib.lib()
+    x = torch.from_numpy(c["lp"]).to(DEV)
+    segs = c["segs"]
+    gh, gd = c["fsa"].blob_host(), c["fsa"].blob_dev(torch.device(DEV))
+    n = C.c_size_t(0)
+    npp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+    _lib.check(lib.wf_fb_workspace_bytes(npp(gh), npp(c["fsa"].utt2fsa), npp(segs), 2, x.shape[2], _lib.WF_PRUNED, 1, C.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=DEV)
+    tot = torch.empty(2, dtype=torch.float32, device=DEV)
+    grad = torch.empty_like(x)
+    args = lambda beam, flags: (npp(gh), C.c_void_p(gd.data_ptr()), npp(c["fsa"].utt2fsa), C.c_void_p(x.data_ptr()), x.stride(0),
+                                x.stride(1), 2, x.shape[1], x.shape[2], npp(segs), 2, beam, flags, None,
+                                C.c_void_p(tot.data_ptr()), C.c_void_p(grad.data_ptr()), C.c_void_p(ws.data_ptr()), n.value, None)
+    assert lib.wf_fb_logsum(*args(5.0, 0)) == -1            # WF_EINVAL: beam without WF_PRUNED
+    assert lib.wf_fb_logsum(*args(0.0, _lib.WF_PRUNED)) == -1
+    _lib.check(lib.wf_fb_logsum(*args(5.0, _lib.WF_PRUNED)))
+    torch.cuda.synchronize()
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], segs, 5.0, "none")
+    np.testing.assert_allclose(-tot.cpu().numpy(), want, rtol=TOT_RTOL, atol=1e-3)
+    np.testing.assert_allclose(-grad.cpu().numpy(), wgrad, atol=GRAD_ATOL)

@@ -7,12 +7,12 @@ mirrors what ``waterfall/graph.py`` and the ``ctc_k2`` / ``k2`` branches of ``wa
 import from k2.  All arithmetic runs in libwfdwfst.so (HIP, gfx950).
 """
 from .fsa import Fsa, DenseFsaVec, create_fsa_vec
-from .graph import GraphLoss, graphloss, tot_scores, best_path
+from .graph import GraphLoss, graphloss, tot_scores, best_path, set_output_beam_mode
 from .compile import linear_fsa, remove_epsilon_and_add_self_loops, arc_sort, compose, compile_ctc_k2_graphs
 from .topology import build_topology, topology_text, Topology, TOPOLOGIES
 
 __all__ = [
-    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path",
+    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path", "set_output_beam_mode",
     "linear_fsa", "remove_epsilon_and_add_self_loops", "arc_sort", "compose", "compile_ctc_k2_graphs",
     "build_topology", "topology_text", "Topology", "TOPOLOGIES",
 ]

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libwfdwfst.so")
 WF_DOUBLE_ACC = 1
 WF_TROPICAL = 2
 WF_KEEP_AB = 4
+WF_PRUNED = 8
 
 
 class WfError(RuntimeError):

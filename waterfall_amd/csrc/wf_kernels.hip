@@ -49,7 +49,7 @@ constexpr int kMaxChunk = 32; // frames per emission chunk
 constexpr int kMaxHeavy = 16; // heavy states reduced per cooperative round
 constexpr size_t kLdsBudget = 160 * 1024;  // one workgroup may own the CU's whole LDS (MI355X: 160 KiB)
 
-enum SweepMode { M_FB = 0, M_TOT_LOG = 1, M_TOT_MAX = 2, M_VITERBI = 3 };
+enum SweepMode { M_FB = 0, M_TOT_LOG = 1, M_TOT_MAX = 2, M_VITERBI = 3, M_FB_MAX = 4 };   // M_FB_MAX: tropical, both directions, rows kept
 
 // ------------------------------------------------------------------------------------------
 // semiring arithmetic
@@ -105,6 +105,14 @@ struct SweepArgs {
     const double* cmax;   // linear sweep: c_t per (utterance, frame) row, natural log units
     double* ctot2;        // linear sweep: sum_t c_t in log2 units, per utterance
     const int32_t* flag;  // fallback sweep: only utterances with flag[u] != 0 are processed
+    // output_beam pruning: tropical alpha^ / beta^ rows of the first pass, the tropical best score per
+    // utterance, the beam; the masked log-semiring pass keeps lattice arc (t, a) iff
+    // alpha^_t[src] + x + beta^_{t+1}[dst] >= best - beam and leaves thr[u] = best - beam for the post kernel
+    const float* mA;
+    const float* mB;
+    const float* best;
+    float* thr;
+    float beam;
     int32_t* bp;   // viterbi back-pointers, arena int32: [utt](T x S)
     int32_t* fin_arc;  // viterbi: best final arc per utterance [B]
     int chunk;     // frames per emission chunk (ESTAGE)
@@ -144,11 +152,18 @@ struct ArcsGlobal {
 
 // One frame step over the states owned by this thread + cooperative heavy states.
 // cur/nxt: LDS alpha buffers; erow(col) returns the emission of column col for this frame.
-template <typename Acc, typename Sum, bool TROP, typename Arcs, typename ERow>
+template <typename Acc, typename Sum, bool TROP, bool MASK, typename Arcs, typename ERow>
 __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, const Acc* cur, Acc* nxt,
                                            int S, int nheavy, int hcap, const int32_t* heavy, Acc* red,
                                            int* red_arc, const int32_t* arc_id, int32_t* bp_row,
-                                           Acc* store_row) {
+                                           Acc* store_row, const float* mrow_a = nullptr, const float* mrow_b = nullptr,
+                                           float thr = 0.f, int dir = 0) {
+    // MASK: lattice arc kept iff alpha^_t[src] + x + beta^_{t+1}[dst] >= thr (mrow_a = alpha^_t, mrow_b = beta^_{t+1};
+    // `oth` is the arc's source in the forward sweep and its destination in the backward sweep)
+    auto kept = [&](int st, int oth, float x) {
+        const float v = dir ? mrow_a[st] + x + mrow_b[oth] : mrow_a[oth] + x + mrow_b[st];
+        return v >= thr;
+    };
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     // ---- heavy states: every thread takes a strided slice of the arc list
@@ -163,7 +178,9 @@ __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, c
             for (int a = a0 + tid; a < a1; a += nt) {
                 int oth, col; float w;
                 arcs.get(a, oth, col, w);
-                Acc v = cur[oth] + (Acc)(w + erow(col));
+                const float x = w + erow(col);
+                Acc v = cur[oth] + (Acc)x;
+                if (MASK && !kept(h, oth, x)) v = neg_inf<Acc>();
                 if (TROP) max_push(m, barc, v, arc_id ? arc_id[a] : a);
                 else lse_push(m, s, v);
             }
@@ -208,7 +225,9 @@ __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, c
         for (int a = a0; a < a1; ++a) {
             int oth, col; float w;
             arcs.get(a, oth, col, w);
-            Acc v = cur[oth] + (Acc)(w + erow(col));
+            const float x = w + erow(col);
+            Acc v = cur[oth] + (Acc)x;
+            if (MASK && !kept(sidx, oth, x)) v = neg_inf<Acc>();
             if (TROP) max_push(m, barc, v, arc_id ? arc_id[a] : a);
             else lse_push(m, s, v);
         }
@@ -228,11 +247,12 @@ struct ERowGlobal {
     __device__ __forceinline__ float operator()(int col) const { return p[col]; }
 };
 
-template <typename Acc, typename Sum, int MODE, bool ARCS_LDS, bool ESTAGE>
+template <typename Acc, typename Sum, int MODE, bool ARCS_LDS, bool ESTAGE, bool MASK = false>
 __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr bool TROP = (MODE == M_TOT_MAX || MODE == M_VITERBI);
-    constexpr int NDIR = (MODE == M_FB) ? 2 : 1;
+    constexpr bool TROP = (MODE == M_TOT_MAX || MODE == M_VITERBI || MODE == M_FB_MAX);
+    constexpr bool ROWS = (MODE == M_FB || MODE == M_FB_MAX);   // both directions, every row kept
+    constexpr int NDIR = ROWS ? 2 : 1;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int u = blockIdx.x / NDIR, dir = blockIdx.x % NDIR;
     if (p.flag && !p.flag[u]) return;   // fallback pass: only the utterances the check flagged
@@ -292,7 +312,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
         for (int s = tid; s < S; s += nt) {
             Acc v = dir ? (Acc)fb[s] : (s == 0 ? (Acc)0 : neg_inf<Acc>());
             cur[s] = v;
-            if (MODE == M_FB) arena[(int64_t)(dir ? T : 0) * S + s] = v;
+            if (ROWS) arena[(int64_t)(dir ? T : 0) * S + s] = v;
         }
     }
 
@@ -332,27 +352,30 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
         for (int step = c * steps_per_chunk; step < step_end; ++step) {
             const int f = frame_of(step);
             // row written this step: forward -> alpha_{f+1}; backward -> beta_f
-            Acc* store_row = (MODE == M_FB) ? arena + (int64_t)(dir ? f : f + 1) * S : nullptr;
+            Acc* store_row = ROWS ? arena + (int64_t)(dir ? f : f + 1) * S : nullptr;
+            const float* mra = MASK ? p.mA + U[WF_U_ALPHA] + (int64_t)f * S : nullptr;
+            const float* mrb = MASK ? p.mB + U[WF_U_BETA] + (int64_t)(f + 1) * S : nullptr;
+            const float mthr = MASK ? p.best[u] - p.beam : 0.f;
             int32_t* bp_row = (MODE == M_VITERBI) ? p.bp + U[WF_U_ALPHA] + (int64_t)f * S : nullptr;
             if (ESTAGE) {
                 ERowLds er{ebuf + (c & 1) * C * p.kpad + (step - c * C) * p.kpad};
                 if (ARCS_LDS) {
                     ArcsLds arcs{larcs, larcs + ((S + 1 + 3) & ~3),
                                  (const float*)(larcs + ((S + 1 + 3) & ~3) + ((A + 3) & ~3))};
-                    sweep_step<Acc, Sum, TROP>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row);
+                    sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir);
                 } else {
                     ArcsGlobal arcs{g_off, g_oth, g_col, g_w};
-                    sweep_step<Acc, Sum, TROP>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row);
+                    sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir);
                 }
             } else {
                 ERowGlobal er{ebase + (int64_t)f * epitch};
                 if (ARCS_LDS) {
                     ArcsLds arcs{larcs, larcs + ((S + 1 + 3) & ~3),
                                  (const float*)(larcs + ((S + 1 + 3) & ~3) + ((A + 3) & ~3))};
-                    sweep_step<Acc, Sum, TROP>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row);
+                    sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir);
                 } else {
                     ArcsGlobal arcs{g_off, g_oth, g_col, g_w};
-                    sweep_step<Acc, Sum, TROP>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row);
+                    sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir);
                 }
             }
             if (step + 1 == step_end && c + 1 < nchunks) commit_chunk(c + 1);
@@ -393,6 +416,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
             if (p.tot_double) ((double*)p.tot)[u] = (double)val;
             else ((float*)p.tot)[u] = (float)val;
             if (MODE == M_FB && p.totd) p.totd[u] = (double)val;
+            if (MASK && p.thr) p.thr[u] = p.best[u] - p.beam;
             if (MODE == M_VITERBI) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
         }
     }
@@ -1573,6 +1597,9 @@ struct PostArgs {
     int lin;        // != 0: the call used sweep_lin_kernel (rows are scaled probabilities, fp64, + per-group
                     // shifts); the value is the sweep's frames per rescale group
     int lag;        // see lin_shift_index
+    const float* mA;   // output_beam pruning: tropical alpha^ / beta^ rows and the per-utterance threshold (null: no pruning)
+    const float* mB;
+    const float* thr;
     const double* aoff;
     const double* boff;
 };
@@ -1697,6 +1724,10 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
         }
         const int64_t arow = (int64_t)t * S, brow = (int64_t)(t + 1) * S;
         const float* erow = ebase + (int64_t)t * epitch;
+        const bool masked = p.mA != nullptr;
+        const float* mra = masked ? p.mA + U[WF_U_ALPHA] + arow : nullptr;
+        const float* mrb = masked ? p.mB + U[WF_U_BETA] + brow : nullptr;
+        const float mthr = masked ? p.thr[u] : 0.f;
         // reference point: the best alpha of this frame, so that both LDS vectors hold small numbers
         double mx = (double)-INFINITY;
         double ca = pa, cb = pb;
@@ -1743,7 +1774,9 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
             for (int a = tid; a < A; a += nt) {
                 const int c = lcol[a];
                 const float e = stage_e ? le[c] : erow[c];
-                lpost[a] = __builtin_amdgcn_exp2f((la[lsrc[a]] + lb[ldst[a]]) * xs + (lw[a] + e) * es);
+                float pv = __builtin_amdgcn_exp2f((la[lsrc[a]] + lb[ldst[a]]) * xs + (lw[a] + e) * es);
+                if (masked && !(mra[lsrc[a]] + (lw[a] + e) + mrb[ldst[a]] >= mthr)) pv = 0.f;   // pruned lattice arc
+                lpost[a] = pv;
             }
             __syncthreads();
             for (int k = tid; k < K; k += nt) {
@@ -1758,7 +1791,9 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
                 const float e = stage_e ? le[k] : erow[k];
                 float acc = 0.f;
                 for (int a = a0; a < a1; ++a) {
-                    acc += __builtin_amdgcn_exp2f((la[lsrc[a]] + lb[ldst[a]]) * xs + (lw[a] + e) * es);   // 0 for dead states
+                    float pv = __builtin_amdgcn_exp2f((la[lsrc[a]] + lb[ldst[a]]) * xs + (lw[a] + e) * es);   // 0 for dead states
+                    if (masked && !(mra[lsrc[a]] + (lw[a] + e) + mrb[ldst[a]] >= mthr)) pv = 0.f;   // pruned lattice arc
+                    acc += pv;
                 }
                 grow[direct ? k : labels[k]] = gs * acc;
             }
@@ -1958,6 +1993,8 @@ struct Plan {
     int over_deg_in = 0, over_deg_out = 0;
     int64_t n_E = 0, n_ab = 0, n_P = 0, n_rows = 0;
     bool lin = false;   // forward-backward by a linear-domain sweep (decided in make_plan)
+    bool pruned = false;   // output_beam pruning: tropical rows + thresholds live in the workspace
+    size_t off_mA = 0, off_mB = 0, off_best = 0, off_thr = 0;
     int band_bw = 0, band_sn = 0, band_m = 1;
     bool band_we = true;   // every arc weight of every graph is 0   // banded form: widest band / most positions (band_bw < 0: some graph is not banded)
     int Tlong = 0;
@@ -1982,7 +2019,7 @@ BandSel band_config(const Plan& P);
 
 // dbl_exact: WF_DOUBLE_ACC (k2 use_double_scores=True): exp/log in fp64 too, log-semiring sweep only
 int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V,
-              int num_seqs, size_t acc_bytes, int mode, Plan* P, bool dbl_exact = false) {
+              int num_seqs, size_t acc_bytes, int mode, Plan* P, bool dbl_exact = false, bool pruned = false) {
     int rc = check_blob(graph_host);
     if (rc) return rc;
     if (B < 1 || !seg || V < 1) return wf_fail(WF_EINVAL, "bad B/seg/V");
@@ -2042,7 +2079,8 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     P->off_tot2 = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
     if (mode == 0) {
-        P->lin = acc_bytes == 8 && !dbl_exact && (band_config(*P).ok || lin_config(*P).ok);
+        P->pruned = pruned;
+        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && (band_config(*P).ok || lin_config(*P).ok);
         P->off_ctot2 = o; o = align_up(o + sizeof(double) * B, 256);
         P->off_flag = o; o = align_up(o + sizeof(int32_t) * B, 256);
         if (P->lin) {
@@ -2051,6 +2089,12 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         }
         P->off_alpha = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
         P->off_beta = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
+        if (pruned) {
+            P->off_mA = o; o = align_up(o + sizeof(float) * (size_t)nab, 256);
+            P->off_mB = o; o = align_up(o + sizeof(float) * (size_t)nab, 256);
+            P->off_best = o; o = align_up(o + sizeof(float) * B, 256);
+            P->off_thr = o; o = align_up(o + sizeof(float) * B, 256);
+        }
         P->off_aoff = o; o = align_up(o + sizeof(double) * (size_t)(row0 + B), 256);
         P->off_boff = o; o = align_up(o + sizeof(double) * (size_t)(row0 + B), 256);
     } else if (mode == 2) {
@@ -2143,7 +2187,7 @@ SweepCfg sweep_config_minimal(const Plan& P, size_t acc_bytes) {
 
 template <typename Acc, typename Sum, int MODE>
 int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
-    const int ndir = (MODE == M_FB) ? 2 : 1;
+    const int ndir = (MODE == M_FB || MODE == M_FB_MAX) ? 2 : 1;
     dim3 grid(B * ndir), block(c.threads);
     if (c.lds > kLdsBudget)
         return wf_fail(WF_EUNSUPPORTED, "graph too large for the LDS-resident sweep: %d states need %zu B of LDS (> %zu)",
@@ -2160,6 +2204,19 @@ int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
     else if (c.estage) WF_LAUNCH(false, true);
     else WF_LAUNCH(false, false);
 #undef WF_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+// output_beam pruning, second pass: the log-semiring forward-backward over the kept lattice arcs only
+int launch_sweep_masked(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
+    if (c.lds > kLdsBudget)
+        return wf_fail(WF_EUNSUPPORTED, "graph too large for the LDS-resident sweep: %d states need %zu B of LDS (> %zu)",
+                       c.smax, c.lds, kLdsBudget);
+    auto k = sweep_kernel<double, float, M_FB, false, false, true>;
+    if (c.lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds));
+    hipLaunchKernelGGL(k, dim3(B * 2), dim3(c.threads), c.lds, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
@@ -2299,8 +2356,8 @@ extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2
     const size_t ab = 8;  // log semiring: alpha/beta are always kept in fp64
     int maxseq = 0;
     if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, (need_grad || (flags & WF_KEEP_AB)) ? 0 : 1, &P,
-                       (flags & WF_DOUBLE_ACC) != 0);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, (need_grad || (flags & (WF_KEEP_AB | WF_PRUNED))) ? 0 : 1, &P,
+                       (flags & WF_DOUBLE_ACC) != 0, (flags & WF_PRUNED) != 0);
     if (rc) return rc;
     *bytes = P.total + 256;
     return WF_OK;
@@ -2377,6 +2434,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     }
     q.ctot2 = (const double*)(ws + P.off_ctot2); q.cmax = (const double*)(ws + P.off_cmax);
     q.flag = (const int32_t*)(ws + P.off_flag);
+    if (P.pruned) { q.mA = (const float*)(ws + P.off_mA); q.mB = (const float*)(ws + P.off_mB); q.thr = (const float*)(ws + P.off_thr); }
     q.aoff = (const double*)(ws + P.off_aoff); q.boff = (const double*)(ws + P.off_boff);
     q.blob = (const int32_t*)graph_dev; q.utt = (const int64_t*)(ws + P.off_utt);
     q.seq2utt = (const int32_t*)(ws + P.off_seq2utt);
@@ -2423,22 +2481,23 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
                             uint32_t flags, const float* grad_scale, float* tot, float* grad,
                             void* workspace, size_t workspace_bytes, void* stream) {
     if (!graph_dev || !log_probs || !tot || !workspace) return wf_fail(WF_EINVAL, "wf_fb_logsum: null pointer");
-    if (output_beam > 0 && !std::isinf(output_beam))
-        return wf_fail(WF_EUNSUPPORTED, "wf_fb_logsum: output_beam pruning is not implemented yet; pass <= 0 or inf for the exact sum");
+    const bool pruned = output_beam > 0 && !std::isinf(output_beam);
+    if (pruned != ((flags & WF_PRUNED) != 0))
+        return wf_fail(WF_EINVAL, "wf_fb_logsum: pass WF_PRUNED (also to wf_fb_workspace_bytes / wf_fb_backward) exactly when 0 < output_beam < inf");
     hipStream_t st = (hipStream_t)stream;
     const bool dbl = flags & WF_DOUBLE_ACC;
     const bool need_ab = grad || (flags & WF_KEEP_AB);
     const size_t ab = 8;
     Plan P;
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, need_ab ? 0 : 1, &P, dbl);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, (need_ab || pruned) ? 0 : 1, &P, dbl, pruned);
     if (rc) return rc;
     for (int i = 0; i < B; ++i)
         if (seg[3 * i + 1] + seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d exceeds Tmax=%d", i, Tmax);
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
     std::vector<int32_t> seq2utt;
-    if (need_ab) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
-    rc = upload_tables(P, ws, need_ab ? seq2utt.data() : nullptr, num_seqs, st);
+    if (need_ab || pruned) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
+    rc = upload_tables(P, ws, (need_ab || pruned) ? seq2utt.data() : nullptr, num_seqs, st);
     if (rc) return rc;
     g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = g_tm.have_check = false;
     // Fork: zero-fill the gradient box on the side stream while the sweeps (which occupy only 2B
@@ -2521,6 +2580,22 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
         rc = launch_sweep<double, float, M_FB>(fc, fa, B, st);
         if (rc) return rc;
         if ((rc = tm_record(7, st))) return rc;
+    } else if (pruned) {
+        // pass 1: tropical forward-backward (fp32, every row kept); pass 2: log semiring over the kept arcs
+        SweepCfg tc = sweep_config(P, 4);
+        SweepArgs ta = a;
+        ta.alpha = ws + P.off_mA; ta.beta = ws + P.off_mB; ta.tot = ws + P.off_best; ta.totd = nullptr;
+        ta.chunk = tc.chunk; ta.kpad = tc.kpad; ta.smax = tc.smax; ta.arcs_lds_words = tc.arcs_words; ta.hcap = tc.hcap;
+        rc = launch_sweep<float, float, M_FB_MAX>(tc, ta, B, st);
+        if (rc) return rc;
+        SweepCfg mc = sweep_config_minimal(P, ab);
+        SweepArgs ma = a;
+        ma.mA = (const float*)(ws + P.off_mA); ma.mB = (const float*)(ws + P.off_mB);
+        ma.best = (const float*)(ws + P.off_best); ma.thr = (float*)(ws + P.off_thr); ma.beam = output_beam;
+        ma.chunk = mc.chunk; ma.kpad = mc.kpad; ma.smax = mc.smax; ma.arcs_lds_words = 0; ma.hcap = mc.hcap;
+        rc = launch_sweep_masked(mc, ma, B, st);
+        if (rc) return rc;
+        if ((rc = tm_record(2, st))) return rc;
     } else {
         RegCfg rc_ = (dbl || need_ab) ? RegCfg() : reg_config(P, false);
         if (rc_.ok) rc = launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
@@ -2577,7 +2652,7 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     if (!graph_dev || !log_probs || !tot || !grad || !workspace) return wf_fail(WF_EINVAL, "wf_fb_backward: null pointer");
     const bool dbl = flags & WF_DOUBLE_ACC;
     Plan P;
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P, dbl);
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P, dbl, (flags & WF_PRUNED) != 0);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);

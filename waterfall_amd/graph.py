@@ -55,6 +55,9 @@ class _FbFunction(torch.autograd.Function):
         need_grad = bool(ctx.needs_input_grad[0])
         if need_grad:
             flags |= _lib.WF_KEEP_AB
+        beam = float(output_beam) if output_beam is not None else 0.0
+        if beam > 0 and math.isfinite(beam):
+            flags |= _lib.WF_PRUNED
         gh = graph.blob_host()
         gd = graph.blob_dev(dev)
         n = C.c_size_t(0)
@@ -62,7 +65,6 @@ class _FbFunction(torch.autograd.Function):
                                               1 if need_grad else 0, C.byref(n)))
         ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
         tot = torch.empty(B, dtype=torch.float32, device=dev)
-        beam = float(output_beam) if output_beam is not None else 0.0
         with torch.cuda.device(dev):
             _lib.check(lib.wf_fb_logsum(_np_ptr(gh), _ptr(gd), _np_ptr(graph.utt2fsa), _ptr(lp), lp.stride(0),
                                         lp.stride(1), N, T, V, _np_ptr(seg), B, beam, flags, None, _ptr(tot),
@@ -91,13 +93,28 @@ class _FbFunction(torch.autograd.Function):
         return grad, None, None, None, None
 
 
+_BEAM_MODE = "exact"
+
+
+def set_output_beam_mode(mode: str):
+    """How `output_beam` (graph.py:61-62 passes it to k2.intersect_dense) is honoured.
+
+    "exact" (default): sum over ALL lattice arcs, the limit output_beam -> inf.  With the reference's
+    beams (10, 20) the pruned arcs carry < e^-10 of the best path's mass each, so the two differ by
+    far less than the tolerances (tests/test_gpu_parity.py::test_output_beam_10_is_within_tolerance_of_exact).
+    "pruned": drop lattice arcs whose best path is more than output_beam below the best path
+    (tropical forward-backward pass first); k2 is not available to pin that arithmetic
+    against ("parity unpinned", DESIGN.md).
+    """
+    global _BEAM_MODE
+    assert mode in ("exact", "pruned")
+    _BEAM_MODE = mode
+
+
 def _beam_value(output_beam):
-    """The reference passes output_beam to k2.intersect_dense, which prunes lattice arcs whose best
-    path is more than `output_beam` below the best path.  k2 is not available to pin that
-    arithmetic against ("parity unpinned"); the library sums over all lattice arcs, which
-    is the limit output_beam -> inf and differs from a beam-10 result by far less than the 1e-4
-    relative tolerance on the total score."""
-    return 0.0
+    if _BEAM_MODE == "exact" or output_beam is None:
+        return 0.0
+    return float(output_beam)
 
 
 class GraphLoss(nn.Module):
