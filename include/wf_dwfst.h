@@ -125,6 +125,17 @@ int wf_fb_backward(const void* graph_host, const void* graph_dev, const int32_t*
                    const float* grad_scale, const float* tot, float* grad,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- state posteriors (waterfall/manual_ctc/prior.py:4-55 compute_align) -----------------------
+ * Must follow a wf_fb_logsum(..., flags | WF_KEEP_AB, same graph / seg / workspace) on the same stream.
+ * out: device fp32, element (i, t, s) at i*out_strideB + t*out_strideT + s for segment i, frame t
+ * (relative to the segment's start), state s < Smax:
+ *   log P(path of utterance i is in state s after consuming frame t) = alpha_{t+1}[s] + beta_{t+1}[s] - tot;
+ * -inf for dead / padding states, frames >= the segment's length and infeasible utterances.      */
+int wf_state_posteriors(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                        const int32_t* seg, int32_t B, int32_t V, int32_t num_seqs, uint32_t flags,
+                        float* out, int64_t out_strideB, int64_t out_strideT, int32_t Smax, int32_t Tmax,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- total scores only, log or tropical (lattice_analysis.py:128-129) ------------------------
  * tot: device fp32 [B] (or fp64 [B] when WF_DOUBLE_ACC is set).                                 */
 int wf_tot_scores(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,

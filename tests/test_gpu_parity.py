@@ -427,3 +427,83 @@ def test_output_beam_fused_entry_point_needs_the_flag():
     want, wgrad = o.graphloss(c["ographs"], c["lp"], segs, 5.0, "none")
     np.testing.assert_allclose(-tot.cpu().numpy(), want, rtol=TOT_RTOL, atol=1e-3)
     np.testing.assert_allclose(-grad.cpu().numpy(), wgrad, atol=GRAD_ATOL)
+
+
+# ---- waterfall/manual_ctc drop-in (ctc.py ctc_loss, softmax_ctc.py ctc_softmax, prior.py compute_align) ----
+
+def _manual_ctc_inputs(z):
+    """(trans, transform, trans_lengths) padded as deprecated/datapipe_manual_ctc.py:245-281 pads them."""
+    from oracle import graphs as og
+    V = z["log_probs"].shape[-1]
+    off = z["target_off"]
+    mats = [og.ctc_trans_transform(z["targets"][off[i]:off[i + 1]].tolist(), V) for i in range(len(off) - 1)]
+    S = max(m[0].shape[0] for m in mats)
+    B = len(mats)
+    trans = np.full((B, S, S), og.FMIN, dtype=np.float32)
+    transform = np.full((B, S, V), og.FMIN, dtype=np.float32)
+    lens = np.zeros(B, dtype=np.int64)
+    for b, (t, f) in enumerate(mats):
+        s = t.shape[0]
+        trans[b, :s, :s] = t
+        transform[b, :s] = f
+        lens[b] = s
+    dev = torch.device(DEV)
+    return (torch.from_numpy(trans).to(dev), torch.from_numpy(transform).to(dev), torch.from_numpy(lens).to(dev))
+
+
+@pytest.mark.parametrize("name", ["manual_ctc_ctc_small.npz", "manual_ctc_ctc_medium.npz"])
+def test_manual_ctc_dropin_against_reference_goldens(name):
+    from waterfall_amd import manual_ctc
+    z = util.load_golden(name)
+    trans, transform, lens = _manual_ctc_inputs(z)
+    il = torch.from_numpy(z["input_lengths"])
+    x = torch.from_numpy(z["log_probs"]).to(DEV).requires_grad_(True)
+    loss = manual_ctc.ctc_loss(x, il, trans, lens, transform, reduction="sum")
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["loss_sum"], rtol=TOT_RTOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), z["grad"], atol=GRAD_ATOL)
+    none = manual_ctc.ctc_loss(x.detach(), il, trans, lens, transform, reduction="none")
+    np.testing.assert_allclose(none.cpu().numpy(), z["loss_none"], rtol=TOT_RTOL)
+    mean = manual_ctc.ctc_loss(x.detach(), il, trans, lens, transform, reduction="mean")
+    np.testing.assert_allclose(mean.item(), np.mean(z["loss_none"] / lens.cpu().numpy()), rtol=TOT_RTOL)
+    # eta-semiring (softmax_ctc.py), reference argument order: (..., trans, transform, trans_lengths, eta)
+    x2 = torch.from_numpy(z["log_probs"]).to(DEV).requires_grad_(True)
+    l2 = manual_ctc.ctc_softmax(x2, il, trans, transform, lens, eta=float(z["eta"]), reduction="sum")
+    l2.backward()
+    np.testing.assert_allclose(l2.item(), z["eta_loss_sum"], rtol=TOT_RTOL)
+    np.testing.assert_allclose(x2.grad.cpu().numpy(), z["eta_grad"], atol=GRAD_ATOL)
+    # posterior alignment (prior.py): compare as probabilities where the reference's entries are defined
+    al = manual_ctc.compute_align(x.detach(), il, trans, lens, transform).cpu().numpy()
+    ref = z["align"]
+    for b in range(ref.shape[0]):
+        T, S = int(z["input_lengths"][b]), int(lens[b])
+        np.testing.assert_allclose(np.exp(al[b, :T, :S]), np.exp(ref[b, :T, :S]), atol=GRAD_ATOL)
+        np.testing.assert_allclose(np.exp(al[b, :T, :S]).sum(-1), 1.0, atol=2e-3)
+        assert np.all(np.isneginf(al[b, T:]))
+
+
+@pytest.mark.parametrize("topo", ["2state", "mmictc", "3state-skip-2"])
+def test_manual_ctc_dropin_arc_state_encodings(topo):
+    # the same matrices the golden generator fed to the reference's ctc_loss (one machine state per arc,
+    # non-emitting virtual start / end rows)
+    from oracle import graphs as og
+    from waterfall_amd import manual_ctc
+    z = util.load_golden(f"manual_ctc_{topo}.npz")
+    V = z["log_probs"].shape[-1]
+    mats = [og.graph_to_trans_transform(g, V) for g in util.golden_graphs(z)]
+    S = max(m[0].shape[0] for m in mats)
+    B = len(mats)
+    trans = np.full((B, S, S), og.FMIN, dtype=np.float32)
+    transform = np.full((B, S, V), og.FMIN, dtype=np.float32)
+    lens = np.zeros(B, dtype=np.int64)
+    for b, (t, f) in enumerate(mats):
+        s = t.shape[0]
+        trans[b, :s, :s] = t
+        transform[b, :s] = f
+        lens[b] = s
+    x = torch.from_numpy(z["log_probs"]).to(DEV).requires_grad_(True)
+    loss = manual_ctc.ctc_loss(x, torch.from_numpy(z["input_lengths"]), torch.from_numpy(trans).to(DEV),
+                               torch.from_numpy(lens).to(DEV), torch.from_numpy(transform).to(DEV), reduction="sum")
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["loss_sum"], rtol=TOT_RTOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), z["grad"], atol=GRAD_ATOL)

@@ -47,6 +47,7 @@ _SIGS = {
                                _p, _p, _p, _p, _sz, _p]),
     "wf_fb_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, _u32,
                                  _p, _p, _p, _p, _sz, _p]),
+    "wf_state_posteriors": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _u32, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
     "wf_tot_scores": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _u32, _p, _p, _sz, _p]),
     "wf_timing_enable": (C.c_int, [C.c_int]),
     "wf_timing_read": (C.c_int, [C.POINTER(C.c_float)]),

@@ -1486,6 +1486,64 @@ __global__ void __launch_bounds__(64) check_kernel(CheckArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// State posteriors (waterfall/manual_ctc/prior.py:4-55 compute_align): out[u, t, s] = log of the
+// probability that utterance u's path is in state s after consuming frame t,
+// alpha_{t+1}[s] + beta_{t+1}[s] - tot; -inf for dead states, padding states, frames >= T and
+// infeasible utterances.  One wavefront per (frame, utterance); reads the rows a wf_fb_logsum(WF_KEEP_AB)
+// call left in the workspace, in whichever format the sweep (or the fallback) wrote them.
+// ------------------------------------------------------------------------------------------
+struct StatePostArgs {
+    const int64_t* utt;
+    const double* alpha;
+    const double* beta;
+    const double* aoff;
+    const double* boff;
+    const double* tot2;
+    const double* ctot2;
+    const double* totd;
+    const int32_t* flag;
+    int lin, grp, lag;
+    float* out;
+    int64_t strideB, strideT;
+    int Smax, Tmax;
+};
+
+__global__ void __launch_bounds__(64) state_post_kernel(StatePostArgs p) {
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x, u = blockIdx.y;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int T = (int)U[WF_U_T], S = (int)U[WF_U_S];
+    float* orow = p.out + (int64_t)u * p.strideB + (int64_t)t * p.strideT;
+    const double tot = p.totd[u];
+    if (t >= T || tot == (double)-INFINITY) {
+        for (int s = lane; s < p.Smax; s += 64) orow[s] = -INFINITY;
+        return;
+    }
+    const int r = t + 1;   // row index: after frame t
+    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)r * S;
+    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)r * S;
+    const bool lin = p.lin && !p.flag[u];
+    const double cst = lin ? p.ctot2[u] - p.tot2[u] - p.aoff[U[WF_U_OFFS] + lin_shift_index(r - 1, p.grp, p.lag)] -
+                                 p.boff[U[WF_U_OFFS] + lin_shift_index(T - 1 - r, p.grp, p.lag)]
+                           : 0.0;
+    for (int s = lane; s < p.Smax; s += 64) {
+        float v = -INFINITY;
+        if (s < S - 1) {
+            if (lin) {
+                double ea, eb;
+                float fa, fb;
+                log2_split(arow[s], ea, fa);
+                log2_split(brow[s], eb, fb);
+                v = ((float)(ea + eb + cst) + (fa + fb)) * 0.6931471805599453f;
+            } else {
+                v = (float)(arow[s] + brow[s] - tot);
+            }
+        }
+        orow[s] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // emission gather (compact graphs)
 // ------------------------------------------------------------------------------------------
 struct GatherArgs {
@@ -2664,6 +2722,34 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     if (rc) return rc;
     if ((rc = tm_record(4, st))) return rc;
     g_tm.have_post = g_tm.on;
+    return WF_OK;
+}
+
+extern "C" int wf_state_posteriors(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                                   const int32_t* seg, int32_t B, int32_t V, int32_t num_seqs, uint32_t flags,
+                                   float* out, int64_t out_strideB, int64_t out_strideT, int32_t Smax, int32_t Tmax,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!graph_dev || !out || !workspace || !seg) return wf_fail(WF_EINVAL, "wf_state_posteriors: null pointer");
+    if (flags & WF_PRUNED) return wf_fail(WF_EUNSUPPORTED, "wf_state_posteriors: not available with output_beam pruning");
+    Plan P;
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P, (flags & WF_DOUBLE_ACC) != 0);
+    if (rc) return rc;
+    if (P.smax > Smax) return wf_fail(WF_ERANGE, "wf_state_posteriors: a graph has %d states but out has room for %d", P.smax, Smax);
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
+    const BandSel bs = band_config(P);
+    StatePostArgs a{};
+    a.utt = (const int64_t*)(ws + P.off_utt);
+    a.alpha = (const double*)(ws + P.off_alpha); a.beta = (const double*)(ws + P.off_beta);
+    a.aoff = (const double*)(ws + P.off_aoff); a.boff = (const double*)(ws + P.off_boff);
+    a.tot2 = (const double*)(ws + P.off_tot2); a.ctot2 = (const double*)(ws + P.off_ctot2);
+    a.totd = (const double*)(ws + P.off_totd); a.flag = (const int32_t*)(ws + P.off_flag);
+    a.lin = P.lin ? 1 : 0;
+    a.grp = !P.lin ? 1 : (bs.ok ? bs.grp : lin_group(lin_config(P)));
+    a.lag = bs.ok ? 0 : 1;
+    a.out = out; a.strideB = out_strideB; a.strideT = out_strideT; a.Smax = Smax; a.Tmax = Tmax;
+    hipLaunchKernelGGL(state_post_kernel, dim3(std::max(Tmax, 1), B), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
     return WF_OK;
 }
 
