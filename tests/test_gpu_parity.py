@@ -507,3 +507,53 @@ def test_manual_ctc_dropin_arc_state_encodings(topo):
     loss.backward()
     np.testing.assert_allclose(loss.item(), z["loss_sum"], rtol=TOT_RTOL)
     np.testing.assert_allclose(x.grad.cpu().numpy(), z["grad"], atol=GRAD_ATOL)
+
+
+# ---- graphs beyond the LDS-resident sweeps (decoding graphs): one launch per frame ----
+
+def _big_case(S, B, T, V=301, seed=5):
+    g = util.synth_decoding_graph(seed, S, V)
+    gen = torch.Generator().manual_seed(seed)
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=gen) * 3.0, -1).numpy()
+    lens = [T, max(1, T - 7), max(1, T // 2), 1][:B] + [T] * max(0, B - 4)
+    segs = np.stack([np.arange(B), np.zeros(B, dtype=np.int64), np.array(lens[:B])], 1).astype(np.int32)
+    return g, lp, segs
+
+
+@pytest.mark.parametrize("S", [12_001, 40_000])
+def test_big_graph_viterbi_bit_exact(oracle_lib, S):
+    g, lp, segs = _big_case(S, B=4, T=40)
+    arcs_ = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
+    one = wf.Fsa(arcs_, g["aux"], [0, arcs_.shape[0]], [g["num_states"]])
+    fsa = wf.create_fsa_vec([one] * 4)                 # one decoding graph shared by the batch
+    assert fsa.utt2fsa is not None
+    dense = wf.DenseFsaVec(torch.from_numpy(lp).to(DEV), torch.from_numpy(segs))
+    out = wf.best_path(fsa, dense)
+    scores, arcs = out["scores"].cpu().numpy(), out["arcs"].cpu().numpy()
+    trop = wf.tot_scores(fsa, dense, log_semiring=False).cpu().numpy()
+    for i in range(4):
+        T = int(segs[i, 2])
+        s, path = util.c_oracle_viterbi(oracle_lib, g, lp[i], T)
+        assert scores[i] == s and trop[i] == s
+        assert list(arcs[i, :T + 1]) == list(path)
+        assert np.all(arcs[i, T + 1:] == -1)
+    s_np, path_np = o.viterbi(g, lp[2], int(segs[2, 2]))     # numpy restatement agrees with the C one
+    assert s_np == scores[2] and list(path_np) == list(arcs[2, :int(segs[2, 2]) + 1])
+
+
+def test_big_graph_tot_scores_log_semiring_and_no_grad_loss():
+    g, lp, segs = _big_case(15_000, B=3, T=30)
+    fsa = util.graphs_to_fsa([g, g, g])                 # per-utterance graphs this time
+    dense = wf.DenseFsaVec(torch.from_numpy(lp).to(DEV), torch.from_numpy(segs))
+    want = np.array([o.forward(g, lp[i], int(segs[i, 2]))[1] for i in range(3)])
+    t32 = wf.tot_scores(fsa, dense, True, False).cpu().numpy()
+    t64 = wf.tot_scores(fsa, dense, True, True).cpu().numpy()
+    np.testing.assert_allclose(t32, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(t64, want, rtol=1e-9)
+    with torch.no_grad():
+        loss = wf.graphloss(fsa, dense, reduction="none").cpu().numpy()
+    np.testing.assert_allclose(loss, -want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    v64 = wf.tot_scores(fsa, dense, False, True).cpu().numpy()
+    for i in range(3):
+        s, _ = o.viterbi(g, lp[i], int(segs[i, 2]), dtype=np.float64)
+        np.testing.assert_allclose(v64[i], s, rtol=1e-12)

@@ -92,5 +92,6 @@ enum {
     WF_U_OFFS = 19,  // element offset of this utterance's per-group scale offsets (<= T+1 doubles)
     WF_U_P = 20,     // element offset of the fp64 emission probabilities (linear-domain sweep)
     WF_U_PP = 21,    // their row pitch in doubles: K rounded up to even, so that rows are 16-byte aligned
+    WF_U_SOFF = 22,  // number of states of the utterances before this one (big-graph sweep: alpha ping-pong buffers)
     WF_U_WORDS = 24,
 };

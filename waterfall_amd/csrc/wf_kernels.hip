@@ -1544,6 +1544,148 @@ __global__ void __launch_bounds__(64) state_post_kernel(StatePostArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Big-graph sweep (graphs whose state vector does not fit the LDS: decoding graphs, SURVEY cfg5):
+// one launch per frame over ALL states of ALL utterances, alpha ping-ponged in HBM/L2, the incoming-arc
+// CSR streamed from memory (it is the dominant traffic: 16 B per arc and frame; utterances that share
+// a graph re-read it from L2 / Infinity Cache).  One lane per state; states with more than
+// WF_HEAVY_DEG incoming arcs get a workgroup each.  Forward only: total scores (log or tropical) and
+// Viterbi back-pointers.  The launch sequence is fixed per call, so a caller may capture it in a HIP graph.
+// ------------------------------------------------------------------------------------------
+struct BigArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const float* lp;
+    int64_t strideB, strideT;
+    const float* E;
+    void* buf;          // [2][nstates] of Acc
+    int64_t nstates;
+    int32_t* bp;        // [utt](T x S) back-pointers (Viterbi) or null
+    int32_t* fin_arc;
+    void* tot;
+    int tot_double;
+    int t;              // frame of this launch
+    int nlb;            // light-state blocks per utterance (max over graphs)
+};
+
+template <typename Acc>
+__global__ void __launch_bounds__(256) big_init_kernel(BigArgs p) {
+    const int u = blockIdx.y;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int S = (int)U[WF_U_S];
+    Acc* cur = (Acc*)p.buf + U[WF_U_SOFF];
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) cur[s] = s == 0 ? (Acc)0 : neg_inf<Acc>();
+}
+
+template <typename Acc, typename Sum, bool TROP>
+__global__ void __launch_bounds__(256) big_step_kernel(BigArgs p) {
+    __shared__ double redv[8];   // (m, s) pairs of 4 waves; Acc <= double
+    __shared__ int reda[4];
+    const int u = blockIdx.y, tid = threadIdx.x;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int T = (int)U[WF_U_T];
+    if (p.t >= T) return;   // ragged batch: this utterance's alpha_T stays in buffer T & 1
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int S = I[WF_I_S], K = I[WF_I_K];
+    const int32_t* off = p.blob + I[WF_I_IN_OFF];
+    const int32_t* src = p.blob + I[WF_I_IN_SRC];
+    const int32_t* col = p.blob + I[WF_I_IN_COL];
+    const float* w = (const float*)(p.blob + I[WF_I_IN_W]);
+    const int32_t* aid = p.blob + I[WF_I_IN_ARC];
+    const Acc* cur = (const Acc*)p.buf + (int64_t)(p.t & 1) * p.nstates + U[WF_U_SOFF];
+    Acc* nxt = (Acc*)p.buf + (int64_t)((p.t + 1) & 1) * p.nstates + U[WF_U_SOFF];
+    const float* erow = I[WF_I_DIRECT] ? p.lp + U[WF_U_SEQ] * p.strideB + (U[WF_U_START] + p.t) * p.strideT
+                                        : p.E + U[WF_U_E] + (int64_t)p.t * K;
+    int32_t* bprow = p.bp ? p.bp + U[WF_U_ALPHA] + (int64_t)p.t * S : nullptr;
+    if ((int)blockIdx.x < p.nlb) {
+        const int s = blockIdx.x * 256 + tid;
+        if (s >= S) return;
+        const int a0 = off[s], a1 = off[s + 1];
+        if (a1 - a0 > WF_HEAVY_DEG) return;   // a workgroup of its own, below
+        Acc m = neg_inf<Acc>();
+        Sum sm = 0;
+        int barc = 0x7fffffff;
+        for (int a = a0; a < a1; ++a) {
+            const Acc v = cur[src[a]] + (Acc)(w[a] + erow[col[a]]);
+            if (TROP) max_push(m, barc, v, aid[a]);
+            else lse_push(m, sm, v);
+        }
+        nxt[s] = TROP ? m : lse_value(m, sm);
+        if (bprow) bprow[s] = (m == neg_inf<Acc>()) ? -1 : barc;
+    } else {
+        const int h = blockIdx.x - p.nlb;
+        if (h >= I[WF_I_NHEAVY_IN]) return;
+        const int s = (p.blob + I[WF_I_HEAVY_IN])[h];
+        const int a0 = off[s], a1 = off[s + 1];
+        Acc m = neg_inf<Acc>();
+        Sum sm = 0;
+        int barc = 0x7fffffff;
+        for (int a = a0 + tid; a < a1; a += 256) {
+            const Acc v = cur[src[a]] + (Acc)(w[a] + erow[col[a]]);
+            if (TROP) max_push(m, barc, v, aid[a]);
+            else lse_push(m, sm, v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const Acc m2 = shfl_xor(m, o);
+            if (TROP) { const int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
+            else { const Sum s2 = shfl_xor(sm, o); lse_merge(m, sm, m2, s2); }
+        }
+        if ((tid & 63) == 0) { redv[(tid >> 6) * 2] = (double)m; redv[(tid >> 6) * 2 + 1] = (double)sm; reda[tid >> 6] = barc; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int x = 1; x < 4; ++x) {
+                if (TROP) max_push(m, barc, (Acc)redv[x * 2], reda[x]);
+                else lse_merge(m, sm, (Acc)redv[x * 2], (Sum)redv[x * 2 + 1]);
+            }
+            nxt[s] = TROP ? m : lse_value(m, sm);
+            if (bprow) bprow[s] = (m == neg_inf<Acc>()) ? -1 : barc;
+        }
+    }
+}
+
+// total score over the final arcs, one workgroup per utterance
+template <typename Acc, typename Sum, bool TROP>
+__global__ void __launch_bounds__(256) big_final_kernel(BigArgs p) {
+    __shared__ double redv[8];
+    __shared__ int reda[4];
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int T = (int)U[WF_U_T];
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const Acc* cur = (const Acc*)p.buf + (int64_t)(T & 1) * p.nstates + U[WF_U_SOFF];
+    const int NF = I[WF_I_NF];
+    const int32_t* fsrc = p.blob + I[WF_I_FIN_SRC];
+    const float* fw = (const float*)(p.blob + I[WF_I_FIN_W]);
+    const int32_t* farc = p.blob + I[WF_I_FIN_ARC];
+    Acc m = neg_inf<Acc>();
+    Sum sm = 0;
+    int barc = 0x7fffffff;
+    for (int i = tid; i < NF; i += 256) {
+        const Acc v = cur[fsrc[i]] + (Acc)fw[i];
+        if (TROP) max_push(m, barc, v, farc[i]);
+        else lse_push(m, sm, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const Acc m2 = shfl_xor(m, o);
+        if (TROP) { const int b2 = shfl_xor(barc, o); max_push(m, barc, m2, b2); }
+        else { const Sum s2 = shfl_xor(sm, o); lse_merge(m, sm, m2, s2); }
+    }
+    if ((tid & 63) == 0) { redv[(tid >> 6) * 2] = (double)m; redv[(tid >> 6) * 2 + 1] = (double)sm; reda[tid >> 6] = barc; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int x = 1; x < 4; ++x) {
+            if (TROP) max_push(m, barc, (Acc)redv[x * 2], reda[x]);
+            else lse_merge(m, sm, (Acc)redv[x * 2], (Sum)redv[x * 2 + 1]);
+        }
+        const Acc val = TROP ? m : lse_value(m, sm);
+        if (p.tot_double) ((double*)p.tot)[u] = (double)val;
+        else ((float*)p.tot)[u] = (float)val;
+        if (p.fin_arc) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // emission gather (compact graphs)
 // ------------------------------------------------------------------------------------------
 struct GatherArgs {
@@ -2053,6 +2195,10 @@ struct Plan {
     bool lin = false;   // forward-backward by a linear-domain sweep (decided in make_plan)
     bool pruned = false;   // output_beam pruning: tropical rows + thresholds live in the workspace
     size_t off_mA = 0, off_mB = 0, off_best = 0, off_thr = 0;
+    bool big = false;       // forward-only call on graphs too large for the LDS sweeps: one launch per frame
+    size_t off_big = 0;
+    int64_t nstates = 0;
+    int nheavy_in_max = 0;
     int band_bw = 0, band_sn = 0, band_m = 1;
     bool band_we = true;   // every arc weight of every graph is 0   // banded form: widest band / most positions (band_bw < 0: some graph is not banded)
     int Tlong = 0;
@@ -2072,6 +2218,7 @@ struct RegCfg {
     size_t lds = 0;
 };
 RegCfg lin_config(const Plan& P);
+size_t sweep_lds_bytes(const Plan& P, size_t acc_bytes);
 struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; };
 BandSel band_config(const Plan& P);
 
@@ -2098,6 +2245,9 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         U[WF_U_FSA] = g; U[WF_U_SEQ] = b; U[WF_U_START] = st; U[WF_U_T] = T;
         U[WF_U_ALPHA] = nab; U[WF_U_BETA] = nab; U[WF_U_E] = nE; U[WF_U_ROW0] = row0;
         U[WF_U_OFFS] = row0 + i;   // sum of (T+1) over the utterances before this one
+        U[WF_U_SOFF] = P->nstates;
+        P->nstates += I[WF_I_S];
+        P->nheavy_in_max = std::max(P->nheavy_in_max, (int)I[WF_I_NHEAVY_IN]);
         U[WF_U_P] = nP;
         U[WF_U_PP] = (I[WF_I_K] + 1) & ~1;
         nP += (int64_t)T * U[WF_U_PP];
@@ -2157,6 +2307,10 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         P->off_boff = o; o = align_up(o + sizeof(double) * (size_t)(row0 + B), 256);
     } else if (mode == 2) {
         P->off_bp = o; o = align_up(o + sizeof(int32_t) * (size_t)nab, 256);
+    }
+    if (mode != 0 && sweep_lds_bytes(*P, acc_bytes) > kLdsBudget) {
+        P->big = true;
+        P->off_big = o; o = align_up(o + 2 * acc_bytes * (size_t)P->nstates, 256);
     }
     P->total = o;
     return WF_OK;
@@ -2241,6 +2395,24 @@ SweepCfg sweep_config_minimal(const Plan& P, size_t acc_bytes) {
     c.estage = false; c.arcs_lds = false; c.chunk = 0; c.arcs_words = 0;
     c.lds = 2 * (size_t)c.smax * acc_bytes + (size_t)c.hcap * 16 * 2 * acc_bytes + (size_t)c.hcap * 16 * 4;
     return c;
+}
+
+size_t sweep_lds_bytes(const Plan& P, size_t acc_bytes) { return sweep_config(P, acc_bytes).lds; }
+
+// big-graph forward sweep: init, one step launch per frame, final reduction
+template <typename Acc, typename Sum, bool TROP>
+int launch_big(const Plan& P, BigArgs a, int B, hipStream_t st) {
+    a.nstates = P.nstates;
+    a.nlb = (P.smax + 255) / 256;
+    const dim3 grid(a.nlb + P.nheavy_in_max, B);
+    hipLaunchKernelGGL(big_init_kernel<Acc>, dim3(std::min(a.nlb, 1024), B), dim3(256), 0, st, a);
+    for (int t = 0; t < P.Tlong; ++t) {
+        a.t = t;
+        hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP>), grid, dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL((big_final_kernel<Acc, Sum, TROP>), dim3(B), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
 }
 
 template <typename Acc, typename Sum, int MODE>
@@ -2655,8 +2827,14 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
     } else {
-        RegCfg rc_ = (dbl || need_ab) ? RegCfg() : reg_config(P, false);
-        if (rc_.ok) rc = launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
+        RegCfg rc_ = (dbl || need_ab || P.big) ? RegCfg() : reg_config(P, false);
+        if (P.big) {
+            // forward only (no gradient asked for) on a graph beyond the LDS sweeps: per-frame launches
+            BigArgs g{};
+            g.blob = a.blob; g.utt = a.utt; g.lp = log_probs; g.strideB = strideB; g.strideT = strideT; g.E = a.E;
+            g.buf = ws + P.off_big; g.tot = tot; g.tot_double = 0;
+            rc = dbl ? launch_big<double, double, false>(P, g, B, st) : launch_big<double, float, false>(P, g, B, st);
+        } else if (rc_.ok) rc = launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
         else if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);
         else rc = dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
         if (rc) return rc;
@@ -2778,6 +2956,13 @@ extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, cons
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
     a.tot = tot; a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap;
     a.tot_double = dbl ? 1 : 0;
+    if (P.big) {
+        BigArgs g{};
+        g.blob = a.blob; g.utt = a.utt; g.lp = log_probs; g.strideB = strideB; g.strideT = strideT; g.E = a.E;
+        g.buf = ws + P.off_big; g.tot = tot; g.tot_double = a.tot_double;
+        if (flags & WF_TROPICAL) return dbl ? launch_big<double, double, true>(P, g, B, st) : launch_big<float, float, true>(P, g, B, st);
+        return dbl ? launch_big<double, double, false>(P, g, B, st) : launch_big<double, float, false>(P, g, B, st);
+    }
     RegCfg rc_ = dbl ? RegCfg() : reg_config(P, false);
     if (rc_.ok) return (flags & WF_TROPICAL) ? launch_sweep_quad<M_TOT_MAX>(rc_, a, B, st)
                                              : launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
@@ -2813,8 +2998,13 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT; a.E = (const float*)(ws + P.off_E);
     a.tot = best_score; a.bp = (int32_t*)(ws + P.off_bp); a.fin_arc = (int32_t*)(ws + P.off_finarc);
     a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
-    RegCfg rc_ = dbl ? RegCfg() : reg_config(P, false);
-    if (rc_.ok) rc = launch_sweep_quad<M_VITERBI>(rc_, a, B, st);
+    RegCfg rc_ = (dbl || P.big) ? RegCfg() : reg_config(P, false);
+    if (P.big) {
+        BigArgs g{};
+        g.blob = a.blob; g.utt = a.utt; g.lp = log_probs; g.strideB = strideB; g.strideT = strideT; g.E = a.E;
+        g.buf = ws + P.off_big; g.tot = best_score; g.tot_double = 0; g.bp = a.bp; g.fin_arc = a.fin_arc;
+        rc = dbl ? launch_big<double, double, true>(P, g, B, st) : launch_big<float, float, true>(P, g, B, st);
+    } else if (rc_.ok) rc = launch_sweep_quad<M_VITERBI>(rc_, a, B, st);
     else rc = dbl ? launch_sweep<double, double, M_VITERBI>(c, a, B, st) : launch_sweep<float, float, M_VITERBI>(c, a, B, st);
     if (rc) return rc;
     TraceArgs t{a.blob, a.utt, a.bp, a.fin_arc, nullptr, best_arcs, B, Tmax};
