@@ -150,11 +150,7 @@ def time_steps(wl, steps, warmup, dist, stream, fused_buf):
         wl.step(stream)
         if dist is not None:
             # single fused all-reduce: [loss_sum, n_frames, n_infeasible]
-            ok = torch.isfinite(wl.tot)
-            fused_buf[0] = -torch.where(ok, wl.tot, torch.zeros_like(wl.tot)).sum()
-            fused_buf[1] = float(wl.frames)
-            fused_buf[2] = (~ok).sum()
-            dist.all_reduce(fused_buf)
+            wf.dist.fused_loss_stats(wl.tot, wl.frames, out=fused_buf)
     for _ in range(warmup):
         one()
     if dist is not None:

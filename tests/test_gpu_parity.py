@@ -231,7 +231,7 @@ def test_full_size_against_c_oracle_and_properties(oracle_lib, topo, P, L, den):
     assert np.all(grad <= 0)
 
 
-def test_full_size_mmictc_denominator_properties():
+def test_full_size_mmictc_denominator_properties(oracle_lib):
     # cfg4 (LS BPE-5k mmictc denominator: S=10002, A=30002, fan-in(0)=15001) at reduced batch so the
     # test stays short; checked through properties + a float64 C-oracle pass on two utterances
     c = util.random_case(777, "mmictc", B=4, T=120, L=8, P=5000, den=True)
@@ -240,6 +240,20 @@ def test_full_size_mmictc_denominator_properties():
         T = int(c["segs"][b, 2])
         np.testing.assert_allclose(grad[b, :T].sum(-1), -1.0, atol=2e-3)
         assert np.all(grad[b, T:] == 0)
+    tot_d, grad_d = util.c_oracle_batch(oracle_lib, c["ographs"][:2], c["lp"][:2], c["segs"][:2], gscale=[-1.0] * 2,
+                                        use_double=True, nthreads=2)
+    np.testing.assert_allclose(loss[:2], -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad[:2], grad_d, atol=GRAD_ATOL)
+    # the same sweep with the arcs re-read from memory in every frame (no register copy), the LDS-staged
+    # gradient kernel, and the per-frame-launch sweep: same arithmetic in the same order / same tolerances
+    l2, g2 = _with_env({"WF_NO_ARC_CACHE": "1"}, lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none"))
+    assert np.array_equal(loss, l2) and np.array_equal(grad, g2)
+    l3, g3 = _with_env({"WF_POST_BIG_MIN_S": "1000000"}, lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none"))
+    np.testing.assert_allclose(l3, loss, rtol=1e-6)
+    np.testing.assert_allclose(g3, grad, atol=1e-5)
+    l4, g4 = _with_env({"WF_BIG_MIN_S": "1000"}, lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none"))
+    np.testing.assert_allclose(l4, loss, rtol=1e-6)
+    np.testing.assert_allclose(g4, grad, atol=1e-5)
 
 
 # ---- every sweep implementation behind wf_fb_logsum, on the same inputs ----------------------------
@@ -557,3 +571,47 @@ def test_big_graph_tot_scores_log_semiring_and_no_grad_loss():
     for i in range(3):
         s, _ = o.viterbi(g, lp[i], int(segs[i, 2]), dtype=np.float64)
         np.testing.assert_allclose(v64[i], s, rtol=1e-12)
+
+
+def test_big_graph_loss_and_gradient_against_oracle():
+    g, lp, segs = _big_case(15_000, B=3, T=30)
+    fsa = util.graphs_to_fsa([g, g, g])
+    x = torch.from_numpy(lp).to(DEV).requires_grad_(True)
+    dense = wf.DenseFsaVec(x, torch.from_numpy(segs))
+    loss = wf.graphloss(fsa, dense, reduction="none")
+    loss.sum().backward()
+    want, wgrad = o.graphloss([g, g, g], lp, segs, None, "none")
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    grad = x.grad.cpu().numpy()
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+    # occupation counts: every frame of every utterance carries posterior mass 1
+    for i in range(3):
+        T = int(segs[i, 2])
+        np.testing.assert_allclose(-grad[i, :T].sum(-1), 1.0, rtol=1e-4)
+        assert np.all(grad[i, T:] == 0)
+
+
+@pytest.mark.parametrize("post_big", [0, 1])
+@pytest.mark.parametrize("topo,den", [("ctc", False), ("mmictc", True), ("3state-skip", True), ("2state_sil", False)])
+def test_per_frame_launch_sweep_forced_on_the_training_topologies(topo, den, post_big):
+    c = util.random_case(61, topo, B=4, T=37, L=6, P=9, den=den)
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+
+    def run():
+        x = torch.from_numpy(c["lp"]).to(DEV).requires_grad_(True)
+        dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
+        loss = wf.graphloss(c["fsa"], dense, reduction="none")
+        loss.sum().backward()
+        best = wf.best_path(c["fsa"], dense)
+        return loss.detach().cpu().numpy(), x.grad.cpu().numpy(), best
+
+    loss, grad, best = _with_env({"WF_BIG_MIN_S": "1", "WF_POST_BIG_MIN_S": "1" if post_big else "1000000"}, run)
+    np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+    base = c["fsa"].fsa_arc_offsets
+    for i, g in enumerate(c["ographs"]):
+        T = int(c["segs"][i, 2])
+        s, path = o.viterbi(g, c["lp"][i], T)
+        gi = 0 if c["fsa"].utt2fsa is not None else i
+        assert best["scores"][i].item() == s
+        assert list(best["arcs"][i, :T + 1].cpu().numpy() - base[gi]) == path

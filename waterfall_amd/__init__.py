@@ -10,10 +10,11 @@ from .fsa import Fsa, DenseFsaVec, create_fsa_vec
 from .graph import GraphLoss, graphloss, tot_scores, best_path, set_output_beam_mode
 from .compile import linear_fsa, remove_epsilon_and_add_self_loops, arc_sort, compose, compile_ctc_k2_graphs
 from . import manual_ctc
+from . import dist
 from .topology import build_topology, topology_text, Topology, TOPOLOGIES
 
 __all__ = [
-    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path", "set_output_beam_mode", "manual_ctc",
+    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path", "set_output_beam_mode", "manual_ctc", "dist",
     "linear_fsa", "remove_epsilon_and_add_self_loops", "arc_sort", "compose", "compile_ctc_k2_graphs",
     "build_topology", "topology_text", "Topology", "TOPOLOGIES",
 ]

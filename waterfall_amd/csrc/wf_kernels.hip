@@ -121,7 +121,9 @@ struct SweepArgs {
     int arcs_lds_words;  // words reserved for the LDS copy of the CSR arrays
     int hcap;      // heavy states reduced per cooperative round (sizes the LDS reduction scratch)
     int tot_double;
-    int ablate;    // measurement aid (WF_SWEEP_PROFILE=1 sets bit 8): workgroup 0 prints its cycles per frame step
+    int ablate;    // measurement aids, never set by the product path: bit 8 (WF_SWEEP_PROFILE=1) workgroup 0 prints its cycles per
+                   // frame step; sweep_kernel, WF_SWEEP_ABLATE: 16 no register copy of streamed arcs, 32 no row stores, 64 no heavy
+                   // states, 128 no light states (32-128 give wrong results: timing only)
 };
 
 // arc accessors: CSR arrays either in LDS (packed 16+16) or in global memory
@@ -157,7 +159,7 @@ __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, c
                                            int S, int nheavy, int hcap, const int32_t* heavy, Acc* red,
                                            int* red_arc, const int32_t* arc_id, int32_t* bp_row,
                                            Acc* store_row, const float* mrow_a = nullptr, const float* mrow_b = nullptr,
-                                           float thr = 0.f, int dir = 0) {
+                                           float thr = 0.f, int dir = 0, bool skip_light = false) {
     // MASK: lattice arc kept iff alpha^_t[src] + x + beta^_{t+1}[dst] >= thr (mrow_a = alpha^_t, mrow_b = beta^_{t+1};
     // `oth` is the arc's source in the forward sweep and its destination in the backward sweep)
     auto kept = [&](int st, int oth, float x) {
@@ -175,14 +177,30 @@ __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, c
             Acc m = neg_inf<Acc>();
             Sum s = 0;
             int barc = 0x7fffffff;
-            for (int a = a0 + tid; a < a1; a += nt) {
-                int oth, col; float w;
-                arcs.get(a, oth, col, w);
-                const float x = w + erow(col);
-                Acc v = cur[oth] + (Acc)x;
-                if (MASK && !kept(h, oth, x)) v = neg_inf<Acc>();
-                if (TROP) max_push(m, barc, v, arc_id ? arc_id[a] : a);
-                else lse_push(m, s, v);
+            // kHU arcs per lane and round: their descriptor loads, then their emission gathers, are independent and
+            // in flight together (one arc at a time costs two dependent L2 round trips per arc: with the 15 001-arc hub
+            // of the BPE-5k denominators that was the whole frame step)
+            constexpr int kHU = 8;
+            for (int ab = a0 + tid; ab < a1; ab += nt * kHU) {
+                int oth[kHU], col[kHU];
+                float x[kHU];
+#pragma unroll
+                for (int j = 0; j < kHU; ++j) {
+                    float w;
+                    arcs.get(min(ab + j * nt, a1 - 1), oth[j], col[j], w);
+                    x[j] = w;
+                }
+#pragma unroll
+                for (int j = 0; j < kHU; ++j) x[j] += erow(col[j]);
+#pragma unroll
+                for (int j = 0; j < kHU; ++j) {
+                    const int a = ab + j * nt;
+                    if (a >= a1) break;
+                    Acc v = cur[oth[j]] + (Acc)x[j];
+                    if (MASK && !kept(h, oth[j], x[j])) v = neg_inf<Acc>();
+                    if (TROP) max_push(m, barc, v, arc_id ? arc_id[a] : a);
+                    else lse_push(m, s, v);
+                }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -216,6 +234,7 @@ __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, c
         if (h0 + hcap < nheavy) __syncthreads();
     }
     // ---- ordinary states: one lane per state
+    if (skip_light) return;   // the caller runs sweep_light_cached instead
     for (int sidx = tid; sidx < S; sidx += nt) {
         const int a0 = arcs.begin(sidx), a1 = arcs.begin(sidx + 1);
         if (a1 - a0 > WF_HEAVY_DEG) continue;
@@ -235,6 +254,53 @@ __device__ __forceinline__ void sweep_step(const Arcs& arcs, const ERow& erow, c
         nxt[sidx] = val;
         if (store_row) store_row[sidx] = val;
         if (TROP && bp_row) bp_row[sidx] = (m == neg_inf<Acc>()) ? -1 : barc;
+    }
+}
+
+// Arcs streamed from memory (graphs whose CSR does not fit the LDS next to the alpha buffers, e.g. the
+// BPE-5k denominators with 10 002 states): a thread owns the same states in every frame, so the first
+// kCDeg arcs of each of its (up to kCSlot) states are loaded ONCE and stay in registers; the per-frame
+// loop then has no dependent chain of L2 round trips (offsets -> arc -> alpha / emission) left, only the
+// independent LDS / emission gathers.  Measured on cfg4 (mmictc denominator): see DESIGN.md.
+constexpr int kCSlot = 10, kCDeg = 2, kCHalf = 5;
+struct ArcCache {
+    unsigned mine;           // bit i: slot i is a state this thread writes (not past S, not a heavy state)
+    unsigned more;           // bit i: that state has more than kCDeg arcs (the rest is read from memory)
+    int pk[kCSlot][kCDeg];   // other state | column << 16 ; (0, weight -inf) for the slots beyond the degree
+    float w[kCSlot][kCDeg];
+};
+
+template <typename Acc, typename Sum, typename ERow>
+__device__ __forceinline__ void sweep_light_cached(const ArcCache& c, const ArcsGlobal& arcs, const ERow& erow, const Acc* cur,
+                                                   Acc* nxt, Acc* store_row) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+#pragma unroll
+    for (int h = 0; h < kCSlot; h += kCHalf) {
+        float x[kCHalf][kCDeg];   // the emission gathers of half of the slots in flight at once
+#pragma unroll
+        for (int i = 0; i < kCHalf; ++i)
+#pragma unroll
+            for (int d = 0; d < kCDeg; ++d) x[i][d] = c.w[h + i][d] + erow((c.pk[h + i][d] >> 16) & 0xffff);
+#pragma unroll
+        for (int i = 0; i < kCHalf; ++i) {
+            if (!((c.mine >> (h + i)) & 1)) continue;
+            const int sidx = tid + (h + i) * nt;
+            Acc m = neg_inf<Acc>();
+            Sum s = 0;
+#pragma unroll
+            for (int d = 0; d < kCDeg; ++d) lse_push(m, s, cur[c.pk[h + i][d] & 0xffff] + (Acc)x[i][d]);
+            if ((c.more >> (h + i)) & 1) {
+                const int a0 = arcs.begin(sidx), a1 = arcs.begin(sidx + 1);
+                for (int a = a0 + kCDeg; a < a1; ++a) {
+                    int oth, col; float w;
+                    arcs.get(a, oth, col, w);
+                    lse_push(m, s, cur[oth] + (Acc)(w + erow(col)));
+                }
+            }
+            const Acc val = lse_value(m, s);
+            nxt[sidx] = val;
+            if (store_row) store_row[sidx] = val;
+        }
     }
 }
 
@@ -316,6 +382,29 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
         }
     }
 
+    // ---- register copy of this thread's light arcs (arcs streamed from memory, log semiring, no mask)
+    constexpr bool CACHE = !ARCS_LDS && !ESTAGE && !TROP && !MASK && sizeof(Sum) == 4;   // (the others have no registers to spare)
+    const bool use_cache = CACHE && S <= kCSlot * nt && K < 65536 && S < 65536 && !(p.ablate & 16);
+    ArcCache ac;
+    ac.mine = ac.more = 0;
+    if (use_cache) {
+#pragma unroll
+        for (int i = 0; i < kCSlot; ++i) {
+            const int sidx = tid + i * nt;
+            int a0 = 0, deg = -1;
+            if (sidx < S) { a0 = g_off[sidx]; deg = g_off[sidx + 1] - a0; }
+            if (deg > WF_HEAVY_DEG) deg = -1;
+            if (deg >= 0) ac.mine |= 1u << i;
+            if (deg > kCDeg) ac.more |= 1u << i;
+#pragma unroll
+            for (int d = 0; d < kCDeg; ++d) {
+                const bool on = d < deg;
+                ac.pk[i][d] = on ? (g_oth[a0 + d] | (g_col[a0 + d] << 16)) : 0;
+                ac.w[i][d] = on ? g_w[a0 + d] : -INFINITY;
+            }
+        }
+    }
+
     // ---- emission prefetch state
     const int C = p.chunk;
     float pre[kPF];
@@ -352,7 +441,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
         for (int step = c * steps_per_chunk; step < step_end; ++step) {
             const int f = frame_of(step);
             // row written this step: forward -> alpha_{f+1}; backward -> beta_f
-            Acc* store_row = ROWS ? arena + (int64_t)(dir ? f : f + 1) * S : nullptr;
+            Acc* store_row = (ROWS && !(p.ablate & 32)) ? arena + (int64_t)(dir ? f : f + 1) * S : nullptr;
             const float* mra = MASK ? p.mA + U[WF_U_ALPHA] + (int64_t)f * S : nullptr;
             const float* mrb = MASK ? p.mB + U[WF_U_BETA] + (int64_t)(f + 1) * S : nullptr;
             const float mthr = MASK ? p.best[u] - p.beam : 0.f;
@@ -365,7 +454,8 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
                     sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir);
                 } else {
                     ArcsGlobal arcs{g_off, g_oth, g_col, g_w};
-                    sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir);
+                    sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, (p.ablate & 64) ? 0 : nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir, use_cache);
+                    if (CACHE) { if (use_cache && !(p.ablate & 128)) sweep_light_cached<Acc, Sum>(ac, arcs, er, cur, nxt, store_row); }
                 }
             } else {
                 ERowGlobal er{ebase + (int64_t)f * epitch};
@@ -375,7 +465,8 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
                     sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir);
                 } else {
                     ArcsGlobal arcs{g_off, g_oth, g_col, g_w};
-                    sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir);
+                    sweep_step<Acc, Sum, TROP, MASK>(arcs, er, cur, nxt, S, (p.ablate & 64) ? 0 : nheavy, p.hcap, heavy, red, red_arc, arc_id, bp_row, store_row, mra, mrb, mthr, dir, use_cache);
+                    if (CACHE) { if (use_cache && !(p.ablate & 128)) sweep_light_cached<Acc, Sum>(ac, arcs, er, cur, nxt, store_row); }
                 }
             }
             if (step + 1 == step_end && c + 1 < nchunks) commit_chunk(c + 1);
@@ -1557,45 +1648,65 @@ struct BigArgs {
     const float* lp;
     int64_t strideB, strideT;
     const float* E;
-    void* buf;          // [2][nstates] of Acc
+    void* buf;          // forward-only calls: [2][nstates] of Acc, ping-pong
+    void* alpha;        // forward-backward calls: the (T+1) x S row arenas (every row kept), else null
+    void* beta;
     int64_t nstates;
     int32_t* bp;        // [utt](T x S) back-pointers (Viterbi) or null
     int32_t* fin_arc;
     void* tot;
+    double* totd;
     int tot_double;
     int t;              // frame of this launch
     int nlb;            // light-state blocks per utterance (max over graphs)
 };
 
-template <typename Acc>
+template <typename Acc, bool TROP>
 __global__ void __launch_bounds__(256) big_init_kernel(BigArgs p) {
     const int u = blockIdx.y;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
-    const int S = (int)U[WF_U_S];
-    Acc* cur = (Acc*)p.buf + U[WF_U_SOFF];
-    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) cur[s] = s == 0 ? (Acc)0 : neg_inf<Acc>();
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int S = (int)U[WF_U_S], T = (int)U[WF_U_T];
+    Acc* a0 = p.alpha ? (Acc*)p.alpha + U[WF_U_ALPHA] : (Acc*)p.buf + U[WF_U_SOFF];
+    Acc* bT = p.beta ? (Acc*)p.beta + U[WF_U_BETA] + (int64_t)T * S : nullptr;
+    const float* fb = (const float*)(p.blob + I[TROP ? WF_I_FINB_MAX : WF_I_FINB_LOG]);
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) {
+        a0[s] = s == 0 ? (Acc)0 : neg_inf<Acc>();
+        if (bT) bT[s] = (Acc)fb[s];
+    }
 }
 
-template <typename Acc, typename Sum, bool TROP>
+// DIR 0: alpha_{t+1} from alpha_t over the incoming arcs; DIR 1: beta_t from beta_{t+1} over the outgoing arcs
+template <typename Acc, typename Sum, bool TROP, int DIR>
 __global__ void __launch_bounds__(256) big_step_kernel(BigArgs p) {
     __shared__ double redv[8];   // (m, s) pairs of 4 waves; Acc <= double
     __shared__ int reda[4];
     const int u = blockIdx.y, tid = threadIdx.x;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int T = (int)U[WF_U_T];
-    if (p.t >= T) return;   // ragged batch: this utterance's alpha_T stays in buffer T & 1
+    if (p.t >= T) return;   // ragged batch: this utterance is shorter than the frame of this launch
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
     const int S = I[WF_I_S], K = I[WF_I_K];
-    const int32_t* off = p.blob + I[WF_I_IN_OFF];
-    const int32_t* src = p.blob + I[WF_I_IN_SRC];
-    const int32_t* col = p.blob + I[WF_I_IN_COL];
-    const float* w = (const float*)(p.blob + I[WF_I_IN_W]);
+    const int32_t* off = p.blob + I[DIR ? WF_I_OUT_OFF : WF_I_IN_OFF];
+    const int32_t* oth = p.blob + I[DIR ? WF_I_OUT_DST : WF_I_IN_SRC];
+    const int32_t* col = p.blob + I[DIR ? WF_I_OUT_COL : WF_I_IN_COL];
+    const float* w = (const float*)(p.blob + I[DIR ? WF_I_OUT_W : WF_I_IN_W]);
     const int32_t* aid = p.blob + I[WF_I_IN_ARC];
-    const Acc* cur = (const Acc*)p.buf + (int64_t)(p.t & 1) * p.nstates + U[WF_U_SOFF];
-    Acc* nxt = (Acc*)p.buf + (int64_t)((p.t + 1) & 1) * p.nstates + U[WF_U_SOFF];
+    const Acc* cur;
+    Acc* nxt;
+    if (DIR) {
+        cur = (const Acc*)p.beta + U[WF_U_BETA] + (int64_t)(p.t + 1) * S;
+        nxt = (Acc*)p.beta + U[WF_U_BETA] + (int64_t)p.t * S;
+    } else if (p.alpha) {
+        cur = (const Acc*)p.alpha + U[WF_U_ALPHA] + (int64_t)p.t * S;
+        nxt = (Acc*)p.alpha + U[WF_U_ALPHA] + (int64_t)(p.t + 1) * S;
+    } else {
+        cur = (const Acc*)p.buf + (int64_t)(p.t & 1) * p.nstates + U[WF_U_SOFF];
+        nxt = (Acc*)p.buf + (int64_t)((p.t + 1) & 1) * p.nstates + U[WF_U_SOFF];
+    }
     const float* erow = I[WF_I_DIRECT] ? p.lp + U[WF_U_SEQ] * p.strideB + (U[WF_U_START] + p.t) * p.strideT
                                         : p.E + U[WF_U_E] + (int64_t)p.t * K;
-    int32_t* bprow = p.bp ? p.bp + U[WF_U_ALPHA] + (int64_t)p.t * S : nullptr;
+    int32_t* bprow = (!DIR && p.bp) ? p.bp + U[WF_U_ALPHA] + (int64_t)p.t * S : nullptr;
     if ((int)blockIdx.x < p.nlb) {
         const int s = blockIdx.x * 256 + tid;
         if (s >= S) return;
@@ -1605,23 +1716,23 @@ __global__ void __launch_bounds__(256) big_step_kernel(BigArgs p) {
         Sum sm = 0;
         int barc = 0x7fffffff;
         for (int a = a0; a < a1; ++a) {
-            const Acc v = cur[src[a]] + (Acc)(w[a] + erow[col[a]]);
-            if (TROP) max_push(m, barc, v, aid[a]);
+            const Acc v = cur[oth[a]] + (Acc)(w[a] + erow[col[a]]);
+            if (TROP) max_push(m, barc, v, DIR ? 0 : aid[a]);
             else lse_push(m, sm, v);
         }
         nxt[s] = TROP ? m : lse_value(m, sm);
         if (bprow) bprow[s] = (m == neg_inf<Acc>()) ? -1 : barc;
     } else {
         const int h = blockIdx.x - p.nlb;
-        if (h >= I[WF_I_NHEAVY_IN]) return;
-        const int s = (p.blob + I[WF_I_HEAVY_IN])[h];
+        if (h >= I[DIR ? WF_I_NHEAVY_OUT : WF_I_NHEAVY_IN]) return;
+        const int s = (p.blob + I[DIR ? WF_I_HEAVY_OUT : WF_I_HEAVY_IN])[h];
         const int a0 = off[s], a1 = off[s + 1];
         Acc m = neg_inf<Acc>();
         Sum sm = 0;
         int barc = 0x7fffffff;
         for (int a = a0 + tid; a < a1; a += 256) {
-            const Acc v = cur[src[a]] + (Acc)(w[a] + erow[col[a]]);
-            if (TROP) max_push(m, barc, v, aid[a]);
+            const Acc v = cur[oth[a]] + (Acc)(w[a] + erow[col[a]]);
+            if (TROP) max_push(m, barc, v, DIR ? 0 : aid[a]);
             else lse_push(m, sm, v);
         }
 #pragma unroll
@@ -1652,7 +1763,8 @@ __global__ void __launch_bounds__(256) big_final_kernel(BigArgs p) {
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int T = (int)U[WF_U_T];
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
-    const Acc* cur = (const Acc*)p.buf + (int64_t)(T & 1) * p.nstates + U[WF_U_SOFF];
+    const Acc* cur = p.alpha ? (const Acc*)p.alpha + U[WF_U_ALPHA] + (int64_t)T * I[WF_I_S]
+                             : (const Acc*)p.buf + (int64_t)(T & 1) * p.nstates + U[WF_U_SOFF];
     const int NF = I[WF_I_NF];
     const int32_t* fsrc = p.blob + I[WF_I_FIN_SRC];
     const float* fw = (const float*)(p.blob + I[WF_I_FIN_W]);
@@ -1681,6 +1793,7 @@ __global__ void __launch_bounds__(256) big_final_kernel(BigArgs p) {
         const Acc val = TROP ? m : lse_value(m, sm);
         if (p.tot_double) ((double*)p.tot)[u] = (double)val;
         else ((float*)p.tot)[u] = (float)val;
+        if (p.totd) p.totd[u] = (double)val;
         if (p.fin_arc) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
     }
 }
@@ -1773,6 +1886,8 @@ __global__ void __launch_bounds__(64) gather_lin_kernel(GatherLinArgs p) {
 // ------------------------------------------------------------------------------------------
 // posterior / gradient rows
 // ------------------------------------------------------------------------------------------
+constexpr int kPostHeavyBig = 16;   // post_big_kernel: arcs per column from which a wavefront sums the column
+
 struct PostArgs {
     const int32_t* blob;
     const int64_t* utt;
@@ -2002,6 +2117,74 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     }
 }
 
+// Gradient rows of graphs whose alpha / beta rows do not fit the LDS (log-domain fp64 rows, as the big-graph
+// sweep leaves them): no staging, alpha_t[src] + beta_{t+1}[dst] gathered from memory in fp64 per arc.
+// Columns with up to kPostHeavy arcs: one lane each; heavier ones: summed by a whole wavefront over
+// coalesced slices of the column-sorted arc arrays (fixed reduction tree: bit-stable, no atomics).
+// grid = (Tmax, num_seqs), 256 threads.
+__global__ void __launch_bounds__(256) post_big_kernel(PostArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x, q = blockIdx.y;
+    float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
+    const int V = p.V;
+    const int u = p.seq2utt[q];
+    const bool has = u >= 0;
+    const int64_t* U = p.utt + (int64_t)(has ? u : 0) * WF_U_WORDS;
+    const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
+    const double tot = has ? p.totd[u] : 0.0;
+    const int t = f - start;
+    if (!has || tot == (double)-INFINITY || t < 0 || t >= T) {
+        if (!p.skip_zero) zero_span(grow, V, tid, 256);
+        return;
+    }
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int S = I[WF_I_S], K = I[WF_I_K], direct = I[WF_I_DIRECT];
+    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    const float* erow = direct ? p.lp + (int64_t)q * p.strideB + (int64_t)(start + t) * p.strideT
+                               : p.E + U[WF_U_E] + (int64_t)t * K;
+    const int32_t* loff = p.blob + I[WF_I_LAB_OFF];
+    const int32_t* lsrc = p.blob + I[WF_I_LAB_SRC];
+    const int32_t* ldst = p.blob + I[WF_I_LAB_DST];
+    const float* lw = (const float*)(p.blob + I[WF_I_LAB_W]);
+    const int32_t* labels = p.blob + I[WF_I_LABELS];
+    const float gs = p.gscale ? p.gscale[u] : 1.f;
+    if (!p.skip_zero) {   // columns the graph does not use
+        if (!direct) zero_span(grow, V, tid, 256);
+        else if (K < V) zero_span(grow + K, V - K, tid, 256);
+        if (!direct) __syncthreads();
+    }
+    auto post = [&](int a, float e) {
+        const double x = arow[lsrc[a]] + brow[ldst[a]] - tot;   // -inf for dead states
+        return __builtin_amdgcn_exp2f(((float)x + (lw[a] + e)) * kLog2e);
+    };
+    for (int k0 = wv * 64; k0 < K; k0 += 256) {
+        const int k = k0 + lane;
+        int a0 = 0, a1 = 0;
+        if (k < K) { a0 = loff[k]; a1 = loff[k + 1]; }
+        const bool heavy = a1 - a0 > kPostHeavyBig;
+        if (k < K && !heavy) {
+            const float e = erow[k];
+            float acc = 0.f;
+            for (int a = a0; a < a1; ++a) acc += post(a, e);
+            grow[direct ? k : labels[k]] = gs * acc;
+        }
+        unsigned long long hm = __ballot(heavy);
+        while (hm) {
+            const int j = __builtin_ctzll(hm);
+            hm &= hm - 1;
+            const int kk = k0 + j;
+            const int b0 = __shfl(a0, j), b1 = __shfl(a1, j);
+            const float e = erow[kk];
+            float acc = 0.f;
+            for (int a = b0 + lane; a < b1; a += 64) acc += post(a, e);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += shfl_xor(acc, o);
+            if (lane == 0) grow[direct ? kk : labels[kk]] = gs * acc;
+        }
+    }
+}
+
 // Gradient rows of small compact graphs (numerators: S, K <= 64 * PSS, A <= 128 * PSS), rows pre-zeroed
 // (skip_zero).  One wavefront per kPostFR consecutive frames of one utterance: the arc descriptors are
 // frame-independent and stay in registers, the next frame's alpha / beta / emission values are loaded
@@ -2198,7 +2381,7 @@ struct Plan {
     bool big = false;       // forward-only call on graphs too large for the LDS sweeps: one launch per frame
     size_t off_big = 0;
     int64_t nstates = 0;
-    int nheavy_in_max = 0;
+    int nheavy_in_max = 0, nheavy_out_max = 0;
     int band_bw = 0, band_sn = 0, band_m = 1;
     bool band_we = true;   // every arc weight of every graph is 0   // banded form: widest band / most positions (band_bw < 0: some graph is not banded)
     int Tlong = 0;
@@ -2219,6 +2402,8 @@ struct RegCfg {
 };
 RegCfg lin_config(const Plan& P);
 size_t sweep_lds_bytes(const Plan& P, size_t acc_bytes);
+int env_int(const char* name, int dflt);
+constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where nothing else fits, until measured otherwise
 struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; };
 BandSel band_config(const Plan& P);
 
@@ -2248,6 +2433,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         U[WF_U_SOFF] = P->nstates;
         P->nstates += I[WF_I_S];
         P->nheavy_in_max = std::max(P->nheavy_in_max, (int)I[WF_I_NHEAVY_IN]);
+        P->nheavy_out_max = std::max(P->nheavy_out_max, (int)I[WF_I_NHEAVY_OUT]);
         U[WF_U_P] = nP;
         U[WF_U_PP] = (I[WF_I_K] + 1) & ~1;
         nP += (int64_t)T * U[WF_U_PP];
@@ -2286,9 +2472,13 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     P->off_totd = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_tot2 = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
+    // graphs whose sweep state does not fit the LDS (or, test hook, with at least WF_BIG_MIN_S states): per-frame launches
+    P->big = sweep_lds_bytes(*P, acc_bytes) > kLdsBudget || P->smax >= env_int("WF_BIG_MIN_S", kBigMinStates);
     if (mode == 0) {
+        if (P->big && pruned)
+            return wf_fail(WF_EUNSUPPORTED, "output_beam pruning is not available for graphs beyond the LDS-resident sweeps (%d states)", P->smax);
         P->pruned = pruned;
-        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && (band_config(*P).ok || lin_config(*P).ok);
+        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok);
         P->off_ctot2 = o; o = align_up(o + sizeof(double) * B, 256);
         P->off_flag = o; o = align_up(o + sizeof(int32_t) * B, 256);
         if (P->lin) {
@@ -2308,8 +2498,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     } else if (mode == 2) {
         P->off_bp = o; o = align_up(o + sizeof(int32_t) * (size_t)nab, 256);
     }
-    if (mode != 0 && sweep_lds_bytes(*P, acc_bytes) > kLdsBudget) {
-        P->big = true;
+    if (mode != 0 && P->big) {
         P->off_big = o; o = align_up(o + 2 * acc_bytes * (size_t)P->nstates, 256);
     }
     P->total = o;
@@ -2337,8 +2526,8 @@ int tm_record(int i, hipStream_t st) {
 
 // side stream for work that can overlap the latency-bound sweeps (one per device, per host thread)
 struct Side {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // zero-fill | backward direction of the big-graph sweep
+    hipEvent_t fork = nullptr, join = nullptr, fork2 = nullptr, join2 = nullptr;
 };
 thread_local Side g_side[16];
 int side_get(Side** out) {
@@ -2350,6 +2539,9 @@ int side_get(Side** out) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s.fork2, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.join2, hipEventDisableTiming));
     }
     *out = &s;
     return WF_OK;
@@ -2399,24 +2591,43 @@ SweepCfg sweep_config_minimal(const Plan& P, size_t acc_bytes) {
 
 size_t sweep_lds_bytes(const Plan& P, size_t acc_bytes) { return sweep_config(P, acc_bytes).lds; }
 
-// big-graph forward sweep: init, one step launch per frame, final reduction
+// big-graph sweep: init, one step launch per frame (and, with a.beta set, per direction: the backward
+// launches go to the side stream and run beside the forward ones), final reduction
 template <typename Acc, typename Sum, bool TROP>
 int launch_big(const Plan& P, BigArgs a, int B, hipStream_t st) {
     a.nstates = P.nstates;
     a.nlb = (P.smax + 255) / 256;
+    hipLaunchKernelGGL((big_init_kernel<Acc, TROP>), dim3(std::min(a.nlb, 1024), B), dim3(256), 0, st, a);
+    Side* side = nullptr;
+    if (a.beta) {
+        int rc = side_get(&side);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(side->fork2, st));
+        HIP_TRY(hipStreamWaitEvent(side->stream2, side->fork2, 0));
+        const dim3 gridb(a.nlb + P.nheavy_out_max, B);
+        BigArgs b = a;
+        for (int t = P.Tlong - 1; t >= 0; --t) {
+            b.t = t;
+            hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP, 1>), gridb, dim3(256), 0, side->stream2, b);
+        }
+        HIP_TRY(hipEventRecord(side->join2, side->stream2));
+    }
     const dim3 grid(a.nlb + P.nheavy_in_max, B);
-    hipLaunchKernelGGL(big_init_kernel<Acc>, dim3(std::min(a.nlb, 1024), B), dim3(256), 0, st, a);
     for (int t = 0; t < P.Tlong; ++t) {
         a.t = t;
-        hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP, 0>), grid, dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL((big_final_kernel<Acc, Sum, TROP>), dim3(B), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
+    if (side) HIP_TRY(hipStreamWaitEvent(st, side->join2, 0));
     return WF_OK;
 }
 
 template <typename Acc, typename Sum, int MODE>
-int launch_sweep(const SweepCfg& c, const SweepArgs& a, int B, hipStream_t st) {
+int launch_sweep(const SweepCfg& c, const SweepArgs& a_, int B, hipStream_t st) {
+    SweepArgs a = a_;
+    a.ablate |= env_int("WF_SWEEP_ABLATE", 0);
+    if (env_int("WF_NO_ARC_CACHE", 0)) a.ablate |= 16;   // test hook: streamed arcs re-read in every frame
     const int ndir = (MODE == M_FB || MODE == M_FB_MAX) ? 2 : 1;
     dim3 grid(B * ndir), block(c.threads);
     if (c.lds > kLdsBudget)
@@ -2689,6 +2900,14 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
         HIP_TRY(hipGetLastError());
         return WF_OK;
     }
+    // rows beyond the LDS, or long enough that staging them costs more than gathering per arc (measured on cfg4's
+    // denominators, S = 10 002: 2.4 ms against 3.9 ms): gather from memory.  Log-domain, unpruned rows only.
+    if (lds > kLdsBudget || (!P.lin && !P.pruned && P.smax >= env_int("WF_POST_BIG_MIN_S", 4096))) {
+        if (P.lin || P.pruned) return wf_fail(WF_EUNSUPPORTED, "internal: post_big_kernel needs log-domain, unpruned rows");
+        hipLaunchKernelGGL(post_big_kernel, dim3(Tmax, num_seqs), dim3(256), 0, st, q);
+        HIP_TRY(hipGetLastError());
+        return WF_OK;
+    }
     const bool tiny_rows = skip_zero || V <= 1024;   // a 64-lane workgroup would be slow at zero-filling long rows
     const int threads = (P.amax <= 1024 && P.smax <= 512 && tiny_rows) ? 64 : 256;
     q.fr = 1;
@@ -2829,10 +3048,12 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     } else {
         RegCfg rc_ = (dbl || need_ab || P.big) ? RegCfg() : reg_config(P, false);
         if (P.big) {
-            // forward only (no gradient asked for) on a graph beyond the LDS sweeps: per-frame launches
+            // graph beyond the LDS sweeps: per-frame launches (both directions when alpha/beta rows are wanted)
             BigArgs g{};
             g.blob = a.blob; g.utt = a.utt; g.lp = log_probs; g.strideB = strideB; g.strideT = strideT; g.E = a.E;
-            g.buf = ws + P.off_big; g.tot = tot; g.tot_double = 0;
+            g.tot = tot; g.tot_double = 0;
+            if (need_ab) { g.alpha = a.alpha; g.beta = a.beta; g.totd = a.totd; }
+            else g.buf = ws + P.off_big;
             rc = dbl ? launch_big<double, double, false>(P, g, B, st) : launch_big<double, float, false>(P, g, B, st);
         } else if (rc_.ok) rc = launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
         else if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);

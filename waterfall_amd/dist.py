@@ -1,0 +1,61 @@
+"""Multi-GPU side of the hot path: utterances are independent, so a batch is sharded over
+one process per GPU with NO data-path collective; the only exchange is one fused all-reduce per step of the
+scalars the training loop logs / normalises by (the reference gets the same numbers from Lightning's DDP
+reductions around graph.py:66-76).  The dense gradient stays sharded exactly as under DDP (it feeds each
+rank's own encoder backward).  Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on the GPU
+box, "gloo" in the CPU tests.
+"""
+import numpy as np
+import torch
+
+__all__ = ["shard_batch", "fused_loss_stats", "STATS_FIELDS"]
+
+STATS_FIELDS = ("loss_sum", "n_frames", "n_infeasible")
+
+
+def shard_batch(lengths, world, rank, mode="round_robin"):
+    """Indices (into the batch) of the utterances rank `rank` of `world` processes.
+
+    The reference sorts a batch by length, longest first (datapipe.py:592-615).  "round_robin" deals that order
+    out like cards, so every rank gets the same mix of long and short utterances (the sweep's duration is set by
+    the longest utterance of a shard); "contiguous" cuts the sorted order into `world` runs of equal count.
+    Every utterance lands on exactly one rank; ranks differ by at most one utterance.
+    """
+    lengths = np.asarray(lengths)
+    n = lengths.shape[0]
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    order = np.argsort(-lengths, kind="stable")
+    if mode == "round_robin":
+        return order[rank::world]
+    if mode == "contiguous":
+        base, extra = divmod(n, world)
+        lo = rank * base + min(rank, extra)
+        return order[lo:lo + base + (1 if rank < extra else 0)]
+    raise ValueError(f"unknown shard mode {mode!r}")
+
+
+def fused_loss_stats(tot, n_frames, group=None, grad=None, out=None):
+    """One all-reduce(SUM) of [loss_sum, n_frames, n_infeasible (, sum_{b,t} grad[b,t,:])] over the job.
+
+    tot: [B_local] total scores of this rank's shard (-inf = infeasible utterance: counted, not summed, as the
+    reference's loss would otherwise be inf for the whole job).  n_frames: number of frames of the shard.
+    grad: optional [B_local, T, V] gradient whose per-label column sums are appended (V floats).
+    out: optional preallocated float32 buffer of the right size on tot's device (no allocation in the step).
+    Returns the reduced buffer; `dict(zip(STATS_FIELDS, buf[:3].tolist()))` names the scalars.
+    """
+    import torch.distributed as dist
+    V = grad.shape[-1] if grad is not None else 0
+    if out is None:
+        out = torch.empty(3 + V, dtype=torch.float32, device=tot.device)
+    elif out.numel() != 3 + V or out.dtype != torch.float32:
+        raise ValueError(f"out must be float32 with {3 + V} elements")
+    ok = torch.isfinite(tot)
+    out[0] = -torch.where(ok, tot, torch.zeros_like(tot)).sum()
+    out[1] = float(n_frames)
+    out[2] = (~ok).sum()
+    if V:
+        out[3:] = grad.reshape(-1, V).sum(0)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(out, group=group)
+    return out
