@@ -89,6 +89,26 @@ int wf_compose_linear(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t
                       int32_t* out_arcs, int32_t* out_aux, int32_t* out_num_arcs,
                       int32_t* out_num_states, int32_t arc_capacity);
 
+/* Batched form (one call per training batch; SURVEY.md 8(f) rank 1: the graph compile runs on every step in
+ * front of the loss, models.py:263-270 / datapipe.py:233-256).  The topology is indexed once by (source state,
+ * phone) with wf_topo_index_build (index: caller-allocated int32[wf_topo_index_words]); each product state then
+ * touches only the topology arcs with phone 0 or phone b[i].  Graphs are identical to wf_compose_linear's.
+ * phones / phones_off[B+1]: the transcripts, concatenated.  out_arc_off[B+1], out_num_states[B] are always
+ * written; arcs only when out_arcs != NULL and arc_capacity suffices (else WF_ENOSPC, with out_arc_off[B] =
+ * the number of arcs needed).
+ * ctc_cross != 0: topo is the CTC topology (utils/get_token_fst_ctc.py:25-53) WITHOUT its O(P^2) arcs
+ * "state of another phone -> state of phone p, p : p" (:37-40), which are then implied by phone_state[p] /
+ * phone_token[p] (int32[num_phones], 0 = the phone has no state): 25 M arcs at P = 5000 are never built.   */
+int wf_topo_index_words(int32_t topo_num_arcs, int32_t topo_num_states, int64_t* words);
+int wf_topo_index_build(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs,
+                        int32_t topo_num_states, int32_t* index);
+int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs,
+                            int32_t topo_num_states, const int32_t* index, int32_t ctc_cross,
+                            const int32_t* phone_state, const int32_t* phone_token, int32_t num_phones,
+                            const int32_t* phones, const int32_t* phones_off, int32_t B,
+                            int32_t* out_arcs, int32_t* out_aux, int64_t arc_capacity,
+                            int32_t* out_arc_off, int32_t* out_num_states);
+
 /* ---- workspace ------------------------------------------------------------------------------
  * utt2fsa: host [B] FSA index used by utterance i, or NULL for the identity (B == G); a single
  * shared denominator topology (rnnp.py:91-92) is utt2fsa = {0,0,...}.

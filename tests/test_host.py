@@ -170,3 +170,77 @@ def test_layout_mirror_in_sync_with_header():
     h = open(os.path.join(ROOT, "waterfall_amd", "csrc", "wf_internal.h")).read()
     assert {k: int(v) for k, v in re.findall(r"WF_I_([A-Z_]+) = (\d+)", h)} == L.INFO
     assert int(re.search(r"#define WF_INFO_WORDS (\d+)", h).group(1)) == L.INFO_WORDS
+
+
+def _compose_one_by_one(topo, seqs):
+    """wf_compose_linear (the per-utterance entry point) on the full topology."""
+    lib = _lib.lib()
+    ta, tx = topo.arcs, topo.aux_labels
+    out = []
+    for seq in seqs:
+        seq = np.ascontiguousarray(seq, dtype=np.int32)
+        na, ns = C.c_int32(0), C.c_int32(0)
+        _lib.check(lib.wf_compose_linear(ta.ctypes.data, tx.ctypes.data, ta.shape[0], int(topo.fsa_num_states[0]),
+                                         seq.ctypes.data, len(seq), None, None, C.byref(na), C.byref(ns), 0))
+        oa = np.empty((na.value, 4), dtype=np.int32)
+        ox = np.empty(na.value, dtype=np.int32)
+        _lib.check(lib.wf_compose_linear(ta.ctypes.data, tx.ctypes.data, ta.shape[0], int(topo.fsa_num_states[0]),
+                                         seq.ctypes.data, len(seq), oa.ctypes.data, ox.ctypes.data, C.byref(na),
+                                         C.byref(ns), na.value))
+        out.append((oa, ox, ns.value))
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(wf.TOPOLOGIES))
+def test_batched_compiler_equals_per_utterance_compose(name):
+    rng = np.random.default_rng(5)
+    P = 9
+    phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
+    sil = "sil" in name or "noblk" in name
+    seqs = [[int(x) + 2 for x in rng.integers(0, P, size=L)] for L in (0, 1, 2, 5, 9, 17, 40)]
+    if sil:
+        seqs = [[1] + s + [1] for s in seqs]
+    t = wf.Topology(name, phones)
+    want = _compose_one_by_one(t.fsa, seqs)
+    variants = [wf.Topology(name, phones), wf.Topology(name, phones).fsa]
+    if name == "ctc":                       # the factored form used for large phone tables (implicit O(P^2) arcs)
+        f = wf.Topology(name, phones)
+        f.LAZY_CTC_PHONES = 0
+        assert f.compose_arcs()["ctc_cross"] == 1 and f.compose_arcs()["arcs"].shape[0] == 4 * P + 2
+        variants.append(f)
+    for v in variants:
+        got = wf.compile_ctc_k2_graphs(v, seqs)
+        for i, (oa, ox, ns) in enumerate(want):
+            a0, a1 = got.fsa_arc_offsets[i], got.fsa_arc_offsets[i + 1]
+            assert np.array_equal(got.arcs[a0:a1], oa) and np.array_equal(got.aux_labels[a0:a1], ox), (name, i)
+            assert got.fsa_num_states[i] == ns
+
+
+def test_batched_compiler_large_table_ctc_and_errors():
+    # BPE-5k sized table: the factored CTC topology has 4P+2 arcs instead of P^2+2P+1 (25 M)
+    P = 5000
+    phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
+    t = wf.Topology("ctc", phones)
+    seqs = [[2, 2, 5001, 77], [4999]]
+    vec = wf.compile_ctc_k2_graphs(t, seqs)
+    assert list(vec.fsa_num_states) == [2 * 4 + 2, 2 * 1 + 2]
+    small = wf.Topology("ctc", ["<eps>", "<SIL>", "a", "b", "c"])          # same transcript shape on a tiny table
+    ref = wf.compile_ctc_k2_graphs(small.fsa, [[2, 2, 4, 3], [3]])
+    assert np.array_equal(vec.arcs[:, :2], ref.arcs[:, :2])                  # same structure, other token ids
+    with pytest.raises(_lib.WfError, match="out of range"):
+        wf.compile_ctc_k2_graphs(t, [[5002]])
+    with pytest.raises(ValueError, match=">= 1"):
+        wf.compile_ctc_k2_graphs(t, [[0, 3]])
+    # arc capacity too small: sizes are reported, the caller retries (compile.compose does)
+    lib = _lib.lib()
+    tab = __import__("waterfall_amd.compile", fromlist=["_topo_tables"])._topo_tables(small)
+    flat = np.array([2, 2, 4, 3], dtype=np.int32)
+    off = np.array([0, 4], dtype=np.int32)
+    arc_off = np.zeros(2, dtype=np.int32)
+    ns = np.zeros(1, dtype=np.int32)
+    oa = np.empty((2, 4), dtype=np.int32)
+    ox = np.empty(2, dtype=np.int32)
+    rc = lib.wf_compose_linear_batch(tab["arcs"].ctypes.data, tab["aux"].ctypes.data, tab["arcs"].shape[0], tab["num_states"],
+                                     tab["index"].ctypes.data, 0, None, None, 0, flat.ctypes.data, off.ctypes.data, 1,
+                                     oa.ctypes.data, ox.ctypes.data, 2, arc_off.ctypes.data, ns.ctypes.data)
+    assert rc == -2 and arc_off[1] == ref.fsa_arc_offsets[1] and ns[0] == ref.fsa_num_states[0]

@@ -21,10 +21,12 @@ from .topology import Topology
 class LinearFsaVec:
     """Result of ``linear_fsa``: one label sequence per utterance (labels >= 1; 0 is epsilon)."""
 
-    def __init__(self, seqs, self_loops=False):
-        self.seqs = [np.ascontiguousarray(s, dtype=np.int32).reshape(-1) for s in seqs]
-        for s in self.seqs:
-            if s.size and s.min() < 1:
+    def __init__(self, seqs, self_loops=False, _checked=False):
+        if _checked:
+            self.seqs = seqs
+        else:
+            self.seqs = [np.asarray(s, dtype=np.int32).reshape(-1) for s in seqs]
+            if self.seqs and min((int(s.min()) for s in self.seqs if s.size), default=1) < 1:
                 raise ValueError("linear_fsa labels must be >= 1 (0 is epsilon)")
         self.self_loops = self_loops
 
@@ -43,18 +45,44 @@ def remove_epsilon_and_add_self_loops(fsa):
     """k2.remove_epsilon_and_add_self_loops on a linear FSA: it has no epsilons, so this only adds the
     epsilon self-loops that let topology arcs with an <eps> output stay at the same position."""
     assert isinstance(fsa, LinearFsaVec)
-    return LinearFsaVec(fsa.seqs, self_loops=True)
+    return LinearFsaVec(fsa.seqs, self_loops=True, _checked=True)
 
 
 def arc_sort(fsa):
     return fsa
 
 
-def compose(topo, b, treat_epsilons_specially=False):
-    """k2.compose(topo, linear_with_self_loops, treat_epsilons_specially=False) (models.py:269-270).
+def _topo_tables(topo):
+    """Arc arrays + the (state, phone) index of wf_topo_index_build for a topology; cached on the object."""
+    tab = getattr(topo, "_compose_tables", None)
+    if tab is not None:
+        return tab
+    lib = _lib.lib()
+    if isinstance(topo, Topology):
+        tab = topo.compose_arcs()
+    else:
+        assert topo.num_fsas == 1 and topo.utt2fsa is None, "topology must be a single FSA"
+        tab = {"arcs": np.ascontiguousarray(topo.arcs, dtype=np.int32), "aux": np.ascontiguousarray(topo.aux_labels, dtype=np.int32),
+               "num_states": int(topo.fsa_num_states[0]), "ctc_cross": 0, "phone_state": None, "phone_token": None}
+    nA, nS = tab["arcs"].shape[0], tab["num_states"]
+    n = C.c_int64(0)
+    _lib.check(lib.wf_topo_index_words(nA, nS, C.byref(n)))
+    index = np.empty(n.value, dtype=np.int32)
+    _lib.check(lib.wf_topo_index_build(tab["arcs"].ctypes.data, tab["aux"].ctypes.data, nA, nS, index.ctypes.data))
+    tab["index"] = index
+    try:
+        topo._compose_tables = tab
+    except AttributeError:
+        pass
+    return tab
 
-    topo: the topology Fsa, or a lazy ``Topology`` (restricted per transcript: identical result,
-    needed for the O(P^2) CTC topology at large P).
+
+def compose(topo, b, treat_epsilons_specially=False):
+    """k2.compose(topo, linear_with_self_loops, treat_epsilons_specially=False) (models.py:269-270), for the whole
+    batch in one native call (wf_compose_linear_batch, include/wf_dwfst.h).
+
+    topo: the topology Fsa, or a ``Topology`` (whose large-table CTC form keeps the O(P^2) cross arcs implicit:
+    identical result, 25 M arcs at P = 5000 never built).
     Product states (q, i), numbered in BFS order from (0, 0); topology arc (q -> q', tok : ph) gives
     (q,i) -> (q',i) if ph == 0 and (q,i) -> (q',i+1) if ph == b[i]; final arcs from (q, L) when q is
     final.  Output labels = tokens, aux_labels = phones.
@@ -63,33 +91,32 @@ def compose(topo, b, treat_epsilons_specially=False):
         raise NotImplementedError("the reference always composes with treat_epsilons_specially=False")
     if not isinstance(b, LinearFsaVec) or not b.self_loops:
         raise TypeError("compose expects remove_epsilon_and_add_self_loops(linear_fsa(...)) on the right")
-    lazy = isinstance(topo, Topology)
-    if not lazy:
-        assert topo.num_fsas == 1 and topo.utt2fsa is None, "topology must be a single FSA"
     lib = _lib.lib()
-    arcs_l, aux_l, off, ns = [], [], [0], []
-    for seq in b.seqs:
-        t = topo.restricted(seq) if lazy else topo
-        ta = t.arcs
-        tx = t.aux_labels
-        nA, nS = ta.shape[0], int(t.fsa_num_states[0])
-        na, nst = C.c_int32(0), C.c_int32(0)
-        cap = max(64, 8 * (len(seq) + 2))
-        while True:
-            oa = np.empty((cap, 4), dtype=np.int32)
-            ox = np.empty(cap, dtype=np.int32)
-            rc = lib.wf_compose_linear(ta.ctypes.data, tx.ctypes.data, nA, nS, seq.ctypes.data, len(seq),
-                                       oa.ctypes.data, ox.ctypes.data, C.byref(na), C.byref(nst), cap)
-            if rc == -2 and na.value > cap:  # WF_ENOSPC: sizes were still reported
-                cap = na.value
-                continue
-            _lib.check(rc)
-            break
-        arcs_l.append(oa[:na.value])
-        aux_l.append(ox[:na.value])
-        off.append(off[-1] + na.value)
-        ns.append(nst.value)
-    return Fsa(np.concatenate(arcs_l, 0), np.concatenate(aux_l, 0), off, ns)
+    tab = _topo_tables(topo)
+    B = len(b.seqs)
+    off = np.zeros(B + 1, dtype=np.int32)
+    if B:
+        off[1:] = np.cumsum([s.size for s in b.seqs])
+    flat = np.ascontiguousarray(np.concatenate(b.seqs), dtype=np.int32) if B and off[-1] else np.zeros(1, dtype=np.int32)
+    arc_off = np.zeros(B + 1, dtype=np.int32)
+    ns = np.zeros(max(B, 1), dtype=np.int32)
+    ps, pt = tab["phone_state"], tab["phone_token"]
+    cap = 8 * int(off[-1]) + 16 * B + 64
+    while True:
+        oa = np.empty((cap, 4), dtype=np.int32)
+        ox = np.empty(cap, dtype=np.int32)
+        rc = lib.wf_compose_linear_batch(tab["arcs"].ctypes.data, tab["aux"].ctypes.data, tab["arcs"].shape[0], tab["num_states"],
+                                         tab["index"].ctypes.data, tab["ctc_cross"],
+                                         ps.ctypes.data if ps is not None else None, pt.ctypes.data if pt is not None else None,
+                                         ps.size if ps is not None else 0, flat.ctypes.data, off.ctypes.data, B,
+                                         oa.ctypes.data, ox.ctypes.data, cap, arc_off.ctypes.data, ns.ctypes.data)
+        if rc == -2 and arc_off[B] > cap:  # WF_ENOSPC: sizes were still reported
+            cap = int(arc_off[B])
+            continue
+        _lib.check(rc)
+        break
+    n = int(arc_off[B])
+    return Fsa(oa[:n], ox[:n], arc_off, ns[:B])
 
 
 def compile_ctc_k2_graphs(topo, targets):

@@ -118,13 +118,24 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
     B[WF_H_MAGIC] = WF_BLOB_MAGIC;
     B[WF_H_NUM_FSAS] = gh->num_fsas;
     B[WF_H_WORDS] = (int32_t)(need / 4);
-    size_t cur = pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * gh->num_fsas);
     int gmaxlab = -1, gmaxS = 0, gmaxA = 0;
-    for (int g = 0; g < gh->num_fsas; ++g) {
-        FsaPlan p;
-        std::vector<int> labs;
-        rc = plan_fsa(gh, g, &p, &labs);
+    // plans (validation, sizes) first: every graph's region of the blob is known before its tables are built
+    const int G = gh->num_fsas;
+    std::vector<FsaPlan> plans(G);
+    std::vector<std::vector<int>> all_labs(G);
+    std::vector<size_t> start(G + 1);
+    start[0] = pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * G);
+    for (int g = 0; g < G; ++g) {
+        rc = plan_fsa(gh, g, &plans[g], &all_labs[g]);
         if (rc) return rc;
+        start[g + 1] = start[g] + plans[g].words;
+        gmaxlab = std::max(gmaxlab, plans[g].max_label); gmaxS = std::max(gmaxS, plans[g].S); gmaxA = std::max(gmaxA, plans[g].A);
+    }
+    if (start[G] * 4 > need) return wf_fail(WF_ENOSPC, "internal: blob overflow");
+    for (int g = 0; g < G; ++g) {
+        const FsaPlan& p = plans[g];
+        const std::vector<int>& labs = all_labs[g];
+        size_t cur = start[g];
         int32_t* I = B + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * g;
         const int32_t* arcs = gh->arcs + 4 * (size_t)gh->fsa_arc_offsets[g];
         const int S = p.S, A = p.A;
@@ -132,7 +143,6 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
         I[WF_I_S] = S; I[WF_I_A] = A; I[WF_I_NF] = p.NF; I[WF_I_K] = p.K; I[WF_I_DIRECT] = p.direct;
         I[WF_I_ARC_BASE] = gh->fsa_arc_offsets[g];
         I[WF_I_MAX_LABEL] = p.max_label;
-        gmaxlab = std::max(gmaxlab, p.max_label); gmaxS = std::max(gmaxS, S); gmaxA = std::max(gmaxA, A);
         auto col_of = [&](int label) {
             if (p.direct) return label;
             return (int)(std::lower_bound(labs.begin(), labs.end(), label) - labs.begin());
@@ -322,7 +332,7 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
                 }
             }
         }
-        if (cur * 4 > need) return wf_fail(WF_ENOSPC, "internal: blob overflow");
+        if (cur > start[g + 1]) return wf_fail(WF_ENOSPC, "internal: blob overflow in fsa %d", g);
     }
     B[WF_H_MAX_LABEL] = gmaxlab; B[WF_H_MAX_STATES] = gmaxS; B[WF_H_MAX_ARCS] = gmaxA;
     return WF_OK;
@@ -400,5 +410,200 @@ extern "C" int wf_compose_linear(const int32_t* topo_arcs, const int32_t* topo_a
         }
         ++w;
     }
+    return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched numerator-graph compiler: the product of wf_compose_linear for a whole
+// batch in one call, against a topology indexed once by (source state, phone).  A product state (q, i) then
+// touches only the topology arcs that can match -- phone 0 (stay at position i) and phone b[i] (advance) --
+// instead of every arc leaving q (5 001 for the hub state of a BPE-5k topology).  Results are identical to
+// wf_compose_linear on the same topology: same BFS state numbering, same arc order.
+//
+// Index layout (int32 words): soff[nS+1] | perm[nA] (arc ids, per state stably sorted by phone; final arcs
+// carry key -1) | key[nA] (the phone of perm[j]).
+//
+// ctc_cross != 0: the CTC topology of utils/get_token_fst_ctc.py:25-53 in factored form.  Its O(P^2) arcs
+// "other phone's state -> this phone's state, p : p" (:37-40) are not stored; phone_state[p] / phone_token[p]
+// (0 = phone has no state) describe them, and a product state (q != 0, i) gets the arc to phone_state[b[i]]
+// at the place the explicit arc would have in the (phone, token)-sorted arc list of q.
+// ------------------------------------------------------------------------------------------
+extern "C" int wf_topo_index_words(int32_t nA, int32_t nS, int64_t* words) {
+    if (nA < 1 || nS < 2 || !words) return wf_fail(WF_EINVAL, "wf_topo_index_words: bad argument");
+    *words = (int64_t)nS + 1 + 2 * (int64_t)nA;
+    return WF_OK;
+}
+
+extern "C" int wf_topo_index_build(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA, int32_t nS,
+                                   int32_t* index) {
+    if (!topo_arcs || !topo_aux || nA < 1 || nS < 2 || !index) return wf_fail(WF_EINVAL, "wf_topo_index_build: bad argument");
+    int32_t* soff = index;
+    int32_t* perm = index + nS + 1;
+    int32_t* key = perm + nA;
+    std::fill(soff, soff + nS + 1, 0);
+    for (int a = 0; a < nA; ++a) {
+        const int s = topo_arcs[4 * (size_t)a], d = topo_arcs[4 * (size_t)a + 1];
+        if (s < 0 || s >= nS || d < 0 || d >= nS) return wf_fail(WF_ERANGE, "wf_topo_index_build: topo arc %d state out of range", a);
+        if (a && s < topo_arcs[4 * (size_t)(a - 1)]) return wf_fail(WF_EINVAL, "wf_topo_index_build: topo arcs must be sorted by source state");
+        if (topo_arcs[4 * (size_t)a + 2] >= 0 && topo_aux[a] < 0) return wf_fail(WF_ERANGE, "wf_topo_index_build: topo arc %d has a negative phone", a);
+        soff[s + 1]++;
+    }
+    for (int s = 0; s < nS; ++s) soff[s + 1] += soff[s];
+    for (int a = 0; a < nA; ++a) perm[a] = a;
+    auto ph = [&](int a) { return topo_arcs[4 * (size_t)a + 2] < 0 ? -1 : topo_aux[a]; };
+    for (int s = 0; s < nS; ++s)
+        std::stable_sort(perm + soff[s], perm + soff[s + 1], [&](int x, int y) { return ph(x) < ph(y); });
+    for (int j = 0; j < nA; ++j) key[j] = ph(perm[j]);
+    return WF_OK;
+}
+
+namespace {
+// open-addressing map (q, i) -> product state id, cleared per utterance
+struct PairMap {
+    std::vector<int64_t> k;
+    std::vector<int32_t> v;
+    size_t mask = 0;
+    void reset(size_t want) {
+        size_t n = 64;
+        while (n < 2 * want) n <<= 1;
+        if (k.size() != n) { k.assign(n, -1); v.assign(n, 0); }
+        else std::fill(k.begin(), k.end(), (int64_t)-1);
+        mask = n - 1;
+    }
+    void grow() {
+        std::vector<int64_t> ok;
+        std::vector<int32_t> ov;
+        ok.swap(k); ov.swap(v);
+        k.assign(ok.size() * 2, -1); v.assign(ok.size() * 2, 0);
+        mask = k.size() - 1;
+        for (size_t j = 0; j < ok.size(); ++j)
+            if (ok[j] >= 0) { size_t h = hash(ok[j]); while (k[h] >= 0) h = (h + 1) & mask; k[h] = ok[j]; v[h] = ov[j]; }
+    }
+    size_t hash(int64_t x) const { return (size_t)((uint64_t)x * 0x9E3779B97F4A7C15ull >> 20) & mask; }
+    // returns the id of key x, inserting next_id if absent (inserted = true)
+    int32_t get(int64_t x, int32_t next_id, bool* inserted) {
+        size_t h = hash(x);
+        while (k[h] >= 0) {
+            if (k[h] == x) { *inserted = false; return v[h]; }
+            h = (h + 1) & mask;
+        }
+        k[h] = x; v[h] = next_id; *inserted = true;
+        return next_id;
+    }
+};
+}  // namespace
+
+extern "C" int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA, int32_t nS,
+                                       const int32_t* index, int32_t ctc_cross, const int32_t* phone_state,
+                                       const int32_t* phone_token, int32_t num_phones,
+                                       const int32_t* phones, const int32_t* phones_off, int32_t B,
+                                       int32_t* out_arcs, int32_t* out_aux, int64_t cap, int32_t* out_arc_off,
+                                       int32_t* out_num_states) {
+    if (!topo_arcs || !topo_aux || !index || nA < 1 || nS < 2 || B < 0 || !phones_off || !out_arc_off || !out_num_states)
+        return wf_fail(WF_EINVAL, "wf_compose_linear_batch: bad argument");
+    if (ctc_cross && (!phone_state || !phone_token || num_phones < 1))
+        return wf_fail(WF_EINVAL, "wf_compose_linear_batch: ctc_cross needs the phone -> state / token tables");
+    const int32_t* soff = index;
+    const int32_t* perm = index + nS + 1;
+    const int32_t* key = perm + nA;
+    PairMap id;
+    std::vector<int64_t> order;
+    std::vector<int32_t> arcs, aux;
+    int64_t w = 0;
+    bool fits = out_arcs && out_aux;
+    out_arc_off[0] = 0;
+    for (int b = 0; b < B; ++b) {
+        const int32_t* seq = phones + phones_off[b];
+        const int L = phones_off[b + 1] - phones_off[b];
+        if (L < 0 || (L > 0 && !phones)) return wf_fail(WF_EINVAL, "wf_compose_linear_batch: transcript %d", b);
+        for (int i = 0; i < L; ++i)
+            if (seq[i] < 1 || (ctc_cross && seq[i] >= num_phones))
+                return wf_fail(WF_ERANGE, "wf_compose_linear_batch: transcript %d position %d: phone %d out of range", b, i, seq[i]);
+        id.reset(8 * (size_t)(L + 2));
+        order.clear(); arcs.clear(); aux.clear();
+        auto pkey = [&](int q, int i) { return (int64_t)q * (L + 1) + i; };
+        bool ins;
+        id.get(pkey(0, 0), 0, &ins);
+        order.push_back(pkey(0, 0));
+        auto emit = [&](int head, int q2, int ni, int tok, int32_t wbits, int phv) {
+            if (order.size() * 2 > id.k.size()) id.grow();
+            const int32_t nid = id.get(pkey(q2, ni), (int32_t)order.size(), &ins);
+            if (ins) order.push_back(pkey(q2, ni));
+            arcs.push_back(head); arcs.push_back(nid); arcs.push_back(tok); arcs.push_back(wbits);
+            aux.push_back(phv);
+        };
+        for (size_t head = 0; head < order.size(); ++head) {
+            const int q = (int)(order[head] / (L + 1)), i = (int)(order[head] % (L + 1));
+            const int lo = soff[q], hi = soff[q + 1];
+            // runs of this state's arcs: final (key -1), phone 0, phone b[i]
+            const int32_t* kb = key + lo;
+            const int32_t* ke = key + hi;
+            const int f1 = (int)(std::upper_bound(kb, ke, -1) - key);
+            const int z1 = (int)(std::upper_bound(key + f1, ke, 0) - key);
+            int p0 = hi, p1 = hi, nph = 0;
+            if (i < L) {
+                nph = seq[i];
+                p0 = (int)(std::lower_bound(key + z1, ke, nph) - key);
+                p1 = (int)(std::upper_bound(key + p0, ke, nph) - key);
+            }
+            // implicit CTC arc (q -> phone_state[b[i]], b[i] : b[i])
+            int cq = 0, ctok = 0;
+            const bool cross = ctc_cross && q != 0 && i < L && phone_state[nph] > 0 && phone_state[nph] != q;
+            if (cross) { cq = phone_state[nph]; ctok = phone_token[nph]; }
+            int x = f1, y = p0;
+            if (!cross) {
+                // emitting arcs in topology order: merge the phone-0 run and the phone-b[i] run by arc id
+                while (x < z1 || y < p1) {
+                    const int ax = x < z1 ? perm[x] : INT32_MAX, ay = y < p1 ? perm[y] : INT32_MAX;
+                    if (ax < ay) {
+                        const int32_t* r = topo_arcs + 4 * (size_t)ax;
+                        emit((int)head, r[1], i, r[2], r[3], 0);
+                        ++x;
+                    } else {
+                        const int32_t* r = topo_arcs + 4 * (size_t)ay;
+                        emit((int)head, r[1], i + 1, r[2], r[3], nph);
+                        ++y;
+                    }
+                }
+            } else {
+                // the factored CTC topology is sorted by (phone, token) per state (prepare_ctc.sh: fstarcsort olabel):
+                // phone-0 arcs first, then the phone-b[i] arcs by token, the implicit one among them
+                for (; x < z1; ++x) {
+                    const int32_t* r = topo_arcs + 4 * (size_t)perm[x];
+                    emit((int)head, r[1], i, r[2], r[3], 0);
+                }
+                bool done = false;
+                for (; y < p1; ++y) {
+                    const int32_t* r = topo_arcs + 4 * (size_t)perm[y];
+                    if (!done && r[2] > ctok) { emit((int)head, cq, i + 1, ctok, 0, nph); done = true; }
+                    emit((int)head, r[1], i + 1, r[2], r[3], nph);
+                }
+                if (!done) emit((int)head, cq, i + 1, ctok, 0, nph);
+            }
+            // final arcs of q at the last position: after the emitting arcs of this product state
+            if (i == L)
+                for (int j = lo; j < f1; ++j) {
+                    const int32_t* r = topo_arcs + 4 * (size_t)perm[j];
+                    arcs.push_back((int32_t)head); arcs.push_back(-1); arcs.push_back(-1); arcs.push_back(r[3]);
+                    aux.push_back(-1);
+                }
+        }
+        const int sf = (int)order.size();
+        const int64_t n = (int64_t)aux.size();
+        if (w + n > INT32_MAX) return wf_fail(WF_EUNSUPPORTED, "wf_compose_linear_batch: more than 2^31 arcs");
+        if (fits && w + n <= cap) {
+            for (int64_t a = 0; a < n; ++a) {
+                int32_t* o = out_arcs + 4 * (size_t)(w + a);
+                o[0] = arcs[4 * a]; o[1] = arcs[4 * a + 1] < 0 ? sf : arcs[4 * a + 1]; o[2] = arcs[4 * a + 2]; o[3] = arcs[4 * a + 3];
+                out_aux[w + a] = aux[a];
+            }
+        } else {
+            fits = false;
+        }
+        w += n;
+        out_arc_off[b + 1] = (int32_t)w;
+        out_num_states[b] = sf + 1;
+    }
+    if (!fits) return wf_fail(WF_ENOSPC, "wf_compose_linear_batch: arc capacity %lld < %lld", (long long)cap, (long long)w);
     return WF_OK;
 }

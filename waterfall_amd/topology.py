@@ -246,6 +246,45 @@ class Topology:
             self._fsa = _assemble(self.name, self.phones, self._tok_id, self._ph_id)
         return self._fsa
 
+    # the full CTC topology has P^2 + 2P + 1 arcs: beyond this many phones numerator compilation uses its factored form
+    LAZY_CTC_PHONES = 64
+
+    def compose_arcs(self, factored=None):
+        """Arc tables for compile.compose / wf_compose_linear_batch: the full topology, or (CTC over a large phone
+        table, or factored=True) the CTC topology without the arcs "state of another phone -> state of phone p, p : p"
+        (utils/get_token_fst_ctc.py:37-40), which phone_state / phone_token then describe."""
+        import numpy as np
+        if factored is None:
+            factored = self.name == "ctc" and len(self.phones) > self.LAZY_CTC_PHONES
+        if not factored:
+            f = self.fsa
+            return {"arcs": np.ascontiguousarray(f.arcs, dtype=np.int32), "aux": np.ascontiguousarray(f.aux_labels, dtype=np.int32),
+                    "num_states": int(f.fsa_num_states[0]), "ctc_cross": 0, "phone_state": None, "phone_token": None}
+        if self.name != "ctc":
+            raise ValueError("only the ctc topology has a factored form")
+        keep = [p for p in self.phones if p not in (EPS, BLK, SIL)]      # get_token_fst_ctc.py:31-33
+        n = len(keep)
+        ph = np.array([self._ph_id[p] for p in keep], dtype=np.int32)
+        tok = np.array([self._tok_id[p] for p in keep], dtype=np.int32)
+        blk = self._tok_id[BLK]
+        x = np.arange(1, n + 1, dtype=np.int32)
+        sf = n + 1
+        # per state sorted by (phone, token) as prepare_ctc.sh's fstarcsort leaves it, the final arc last
+        o0 = np.lexsort((tok, ph))
+        rows0 = np.concatenate([[[0, 0, blk, 0]], np.stack([np.zeros(n, np.int32), x[o0], tok[o0], ph[o0]], 1), [[0, sf, -1, -1]]])
+        first_blk = blk < tok                                           # (x -> 0, blk) before (x -> x, p) iff blk's id is smaller
+        r_a = np.stack([x, np.where(first_blk, 0, x), np.where(first_blk, blk, tok), np.zeros(n, np.int32)], 1)
+        r_b = np.stack([x, np.where(first_blk, x, 0), np.where(first_blk, tok, blk), np.zeros(n, np.int32)], 1)
+        r_f = np.stack([x, np.full(n, sf, np.int32), np.full(n, -1, np.int32), np.full(n, -1, np.int32)], 1)
+        rows = np.concatenate([rows0, np.stack([r_a, r_b, r_f], 1).reshape(-1, 4)]).astype(np.int32)
+        arcs = np.ascontiguousarray(np.stack([rows[:, 0], rows[:, 1], rows[:, 2], np.zeros(len(rows), np.int32)], 1), dtype=np.int32)
+        aux = np.ascontiguousarray(rows[:, 3], dtype=np.int32)
+        phone_state = np.zeros(len(self.phones), dtype=np.int32)
+        phone_token = np.zeros(len(self.phones), dtype=np.int32)
+        phone_state[ph] = x
+        phone_token[ph] = tok
+        return {"arcs": arcs, "aux": aux, "num_states": n + 2, "ctc_cross": 1, "phone_state": phone_state, "phone_token": phone_token}
+
     def restricted(self, phone_ids):
         keep = set(int(i) for i in phone_ids)
         sub = [p for i, p in enumerate(self.phones) if i in keep or p in (EPS, SIL)]
