@@ -615,3 +615,38 @@ def test_per_frame_launch_sweep_forced_on_the_training_topologies(topo, den, pos
         gi = 0 if c["fsa"].utt2fsa is not None else i
         assert best["scores"][i].item() == s
         assert list(best["arcs"][i, :T + 1].cpu().numpy() - base[gi]) == path
+
+
+def test_big_graph_shared_by_the_batch_two_groups_all_semirings():
+    # 11 utterances on one decoding graph: two groups of kNB = 8 (the second partly filled), ragged lengths
+    S, B, T = 12_001, 11, 26
+    g, lp, _ = _big_case(S, B=B, T=T, seed=9)
+    lens = np.array([T, T - 1, T - 3, 20, 17, 13, 9, 5, 2, 1, T], dtype=np.int64)
+    segs = np.stack([np.arange(B), np.zeros(B, dtype=np.int64), lens], 1).astype(np.int32)
+    arcs_ = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
+    fsa = wf.create_fsa_vec([wf.Fsa(arcs_, g["aux"], [0, arcs_.shape[0]], [g["num_states"]])] * B)
+    dense = wf.DenseFsaVec(torch.from_numpy(lp).to(DEV), torch.from_numpy(segs))
+
+    def run():
+        out = wf.best_path(fsa, dense)
+        return (out["scores"].cpu().numpy(), out["arcs"].cpu().numpy(),
+                wf.tot_scores(fsa, dense, log_semiring=False).cpu().numpy(),
+                wf.tot_scores(fsa, dense, log_semiring=True).cpu().numpy(),
+                wf.tot_scores(fsa, dense, True, True).cpu().numpy())
+
+    sc, arcs, trop, logt, log64 = run()
+    for i in range(B):
+        Ti = int(lens[i])
+        s, path = o.viterbi(g, lp[i], Ti)
+        assert sc[i] == s and trop[i] == s
+        if len(path):
+            assert list(arcs[i, :Ti + 1]) == list(path) and np.all(arcs[i, Ti + 1:] == -1)
+        else:                                   # no accepting path in so few frames
+            assert s == -np.inf and np.all(arcs[i] == -1)
+        want = o.forward(g, lp[i], Ti)[1]
+        np.testing.assert_allclose(logt[i], want, rtol=TOT_RTOL, atol=TOT_ATOL)
+        np.testing.assert_allclose(log64[i], want, rtol=1e-9)
+    # one utterance per lane (the path of batches with different graphs): identical numbers
+    sc2, arcs2, trop2, logt2, log642 = _with_env({"WF_NO_SHARED_BIG": "1"}, run)
+    assert np.array_equal(sc, sc2) and np.array_equal(arcs, arcs2) and np.array_equal(trop, trop2)
+    assert np.array_equal(logt, logt2) and np.array_equal(log64, log642)

@@ -1659,6 +1659,9 @@ struct BigArgs {
     int tot_double;
     int t;              // frame of this launch
     int nlb;            // light-state blocks per utterance (max over graphs)
+    int shared_S;       // != 0: alpha is in the shared-graph layout [parity][group][state][kNB] (big_step_shared_kernel)
+    int shared_par;     //       and every utterance's alpha_T is in buffer shared_par
+    int shared_groups;
 };
 
 template <typename Acc, bool TROP>
@@ -1754,6 +1757,166 @@ __global__ void __launch_bounds__(256) big_step_kernel(BigArgs p) {
     }
 }
 
+// ---- the same, for a batch that shares ONE graph (a decoding graph: lattice_analysis.py:123-125, cfg5) ------
+// kNB utterances advance together: a lane owns one state for all of them, so every arc descriptor (16 B) is read
+// once per frame instead of once per utterance and frame, and the gathers alpha_t[src] / e_t[col] fetch one
+// full 32-byte sector (kNB floats) each instead of 4 useful bytes of it.  Layouts: alpha [state][kNB],
+// emissions transposed once per call to Et[frame][column][kNB] (big_tr_kernel).  Utterances past their last
+// frame carry their alpha forward unchanged, so after the last launch every utterance's alpha_T sits in buffer
+// Tlong & 1.  Arithmetic and arc order per utterance are those of big_step_kernel (bit-identical results).
+constexpr int kNB = 8;
+
+struct BigSharedArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const float* lp;
+    int64_t strideB, strideT;
+    const float* E;
+    float* Et;          // [group][Tlong][K][kNB]
+    void* buf;          // [2][group][S][kNB] of Acc
+    int32_t* bp;
+    int B, Tlong, S, K, t, nlb;
+};
+
+__global__ void __launch_bounds__(256) big_tr_kernel(BigSharedArgs p) {
+    const int t = blockIdx.x, g = blockIdx.y;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)p.utt[WF_U_FSA] * WF_INFO_WORDS;
+    const int K = p.K, direct = I[WF_I_DIRECT];
+    const float* row[kNB];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        const int u = g * kNB + j;
+        row[j] = nullptr;
+        if (u < p.B) {
+            const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+            if (t < (int)U[WF_U_T])
+                row[j] = direct ? p.lp + U[WF_U_SEQ] * p.strideB + (U[WF_U_START] + t) * p.strideT : p.E + U[WF_U_E] + (int64_t)t * K;
+        }
+    }
+    float4* out = (float4*)(p.Et + ((int64_t)g * p.Tlong + t) * K * kNB);
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float v[kNB];
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) v[j] = row[j] ? row[j][k] : 0.f;
+        out[2 * k] = make_float4(v[0], v[1], v[2], v[3]);
+        out[2 * k + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+template <typename Acc>
+__global__ void __launch_bounds__(256) big_init_shared_kernel(BigSharedArgs p) {
+    Acc* a0 = (Acc*)p.buf + (int64_t)blockIdx.y * p.S * kNB;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)p.S * kNB; i += (int64_t)gridDim.x * 256)
+        a0[i] = i < kNB ? (Acc)0 : neg_inf<Acc>();
+}
+
+template <typename Acc> __device__ __forceinline__ void load8(const Acc* p, Acc* v);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
+    const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<double>(const double* p, double* v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const double2 a = ((const double2*)p)[j]; v[2 * j] = a.x; v[2 * j + 1] = a.y; }
+}
+
+template <typename Acc, typename Sum, bool TROP>
+__global__ void __launch_bounds__(256) big_step_shared_kernel(BigSharedArgs p) {
+    __shared__ double redv[4][kNB][2];
+    __shared__ int reda[4][kNB];
+    const int g = blockIdx.y, tid = threadIdx.x;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)p.utt[WF_U_FSA] * WF_INFO_WORDS;
+    const int S = p.S;
+    const int32_t* off = p.blob + I[WF_I_IN_OFF];
+    const int32_t* src = p.blob + I[WF_I_IN_SRC];
+    const int32_t* col = p.blob + I[WF_I_IN_COL];
+    const float* w = (const float*)(p.blob + I[WF_I_IN_W]);
+    const int32_t* aid = p.blob + I[WF_I_IN_ARC];
+    const int64_t gstride = (int64_t)(gridDim.y) * S * kNB;
+    const Acc* cur = (const Acc*)p.buf + (int64_t)(p.t & 1) * gstride + (int64_t)g * S * kNB;
+    Acc* nxt = (Acc*)p.buf + (int64_t)((p.t + 1) & 1) * gstride + (int64_t)g * S * kNB;
+    const float* et = p.Et + ((int64_t)g * p.Tlong + p.t) * p.K * kNB;
+    // which of the group's utterances still have a frame t (uniform), and where their back-pointer rows are
+    bool act[kNB];
+    int32_t* bprow[kNB];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        const int u = g * kNB + j;
+        act[j] = false;
+        bprow[j] = nullptr;
+        if (u < p.B) {
+            const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+            act[j] = p.t < (int)U[WF_U_T];
+            if (p.bp && act[j]) bprow[j] = p.bp + U[WF_U_ALPHA] + (int64_t)p.t * S;
+        }
+    }
+    Acc m[kNB];
+    Sum sm[kNB];
+    int barc[kNB];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) { m[j] = neg_inf<Acc>(); sm[j] = 0; barc[j] = 0x7fffffff; }
+    auto push_arc = [&](int a) {
+        Acc c[kNB];
+        float e[kNB];
+        load8<Acc>(cur + (int64_t)src[a] * kNB, c);
+        load8<float>(et + (int64_t)col[a] * kNB, e);
+        const float wa = w[a];
+        const int id = TROP ? aid[a] : 0;
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) {
+            const Acc v = c[j] + (Acc)(wa + e[j]);
+            if (TROP) max_push(m[j], barc[j], v, id);
+            else lse_push(m[j], sm[j], v);
+        }
+    };
+    auto finish = [&](int s) {
+        Acc keep[kNB];
+        load8<Acc>(cur + (int64_t)s * kNB, keep);
+        Acc out[kNB];
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) {
+            out[j] = act[j] ? (TROP ? m[j] : lse_value(m[j], sm[j])) : keep[j];
+            if (bprow[j]) bprow[j][s] = (m[j] == neg_inf<Acc>()) ? -1 : barc[j];
+        }
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) nxt[(int64_t)s * kNB + j] = out[j];
+    };
+    if ((int)blockIdx.x < p.nlb) {
+        const int s = blockIdx.x * 256 + tid;
+        if (s >= S) return;
+        const int a0 = off[s], a1 = off[s + 1];
+        if (a1 - a0 > WF_HEAVY_DEG) return;
+        for (int a = a0; a < a1; ++a) push_arc(a);
+        finish(s);
+    } else {
+        const int h = blockIdx.x - p.nlb;
+        if (h >= I[WF_I_NHEAVY_IN]) return;
+        const int s = (p.blob + I[WF_I_HEAVY_IN])[h];
+        const int a0 = off[s], a1 = off[s + 1];
+        for (int a = a0 + tid; a < a1; a += 256) push_arc(a);
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const Acc m2 = shfl_xor(m[j], o);
+                if (TROP) { const int b2 = shfl_xor(barc[j], o); max_push(m[j], barc[j], m2, b2); }
+                else { const Sum s2 = shfl_xor(sm[j], o); lse_merge(m[j], sm[j], m2, s2); }
+            }
+            if ((tid & 63) == 0) { redv[tid >> 6][j][0] = (double)m[j]; redv[tid >> 6][j][1] = (double)sm[j]; reda[tid >> 6][j] = barc[j]; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int j = 0; j < kNB; ++j)
+                for (int x = 1; x < 4; ++x) {
+                    if (TROP) max_push(m[j], barc[j], (Acc)redv[x][j][0], reda[x][j]);
+                    else lse_merge(m[j], sm[j], (Acc)redv[x][j][0], (Sum)redv[x][j][1]);
+                }
+            finish(s);
+        }
+    }
+}
+
 // total score over the final arcs, one workgroup per utterance
 template <typename Acc, typename Sum, bool TROP>
 __global__ void __launch_bounds__(256) big_final_kernel(BigArgs p) {
@@ -1765,6 +1928,11 @@ __global__ void __launch_bounds__(256) big_final_kernel(BigArgs p) {
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
     const Acc* cur = p.alpha ? (const Acc*)p.alpha + U[WF_U_ALPHA] + (int64_t)T * I[WF_I_S]
                              : (const Acc*)p.buf + (int64_t)(T & 1) * p.nstates + U[WF_U_SOFF];
+    int64_t cstride = 1;
+    if (p.shared_S) {
+        cur = (const Acc*)p.buf + ((int64_t)p.shared_par * p.shared_groups + u / 8) * p.shared_S * 8 + (u & 7);
+        cstride = 8;
+    }
     const int NF = I[WF_I_NF];
     const int32_t* fsrc = p.blob + I[WF_I_FIN_SRC];
     const float* fw = (const float*)(p.blob + I[WF_I_FIN_W]);
@@ -1773,7 +1941,7 @@ __global__ void __launch_bounds__(256) big_final_kernel(BigArgs p) {
     Sum sm = 0;
     int barc = 0x7fffffff;
     for (int i = tid; i < NF; i += 256) {
-        const Acc v = cur[fsrc[i]] + (Acc)fw[i];
+        const Acc v = cur[fsrc[i] * cstride] + (Acc)fw[i];
         if (TROP) max_push(m, barc, v, farc[i]);
         else lse_push(m, sm, v);
     }
@@ -2378,8 +2546,10 @@ struct Plan {
     bool lin = false;   // forward-backward by a linear-domain sweep (decided in make_plan)
     bool pruned = false;   // output_beam pruning: tropical rows + thresholds live in the workspace
     size_t off_mA = 0, off_mB = 0, off_best = 0, off_thr = 0;
-    bool big = false;       // forward-only call on graphs too large for the LDS sweeps: one launch per frame
-    size_t off_big = 0;
+    bool big = false;       // graphs too large for the LDS sweeps: one launch per frame
+    bool shared = false;    // ... and the whole batch uses one graph (forward-only calls): kNB utterances per lane
+    bool one_fsa = true;
+    size_t off_big = 0, off_Et = 0;
     int64_t nstates = 0;
     int nheavy_in_max = 0, nheavy_out_max = 0;
     int band_bw = 0, band_sn = 0, band_m = 1;
@@ -2428,6 +2598,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         if (b < 0 || st < 0 || T < 0 || (num_seqs > 0 && b >= num_seqs)) return wf_fail(WF_ERANGE, "segment %d = (%d,%d,%d) out of range", i, b, st, T);
         int64_t* U = &P->utt[(size_t)i * WF_U_WORDS];
         U[WF_U_FSA] = g; U[WF_U_SEQ] = b; U[WF_U_START] = st; U[WF_U_T] = T;
+        if (g != (utt2fsa ? utt2fsa[0] : 0)) P->one_fsa = false;
         U[WF_U_ALPHA] = nab; U[WF_U_BETA] = nab; U[WF_U_E] = nE; U[WF_U_ROW0] = row0;
         U[WF_U_OFFS] = row0 + i;   // sum of (T+1) over the utterances before this one
         U[WF_U_SOFF] = P->nstates;
@@ -2498,7 +2669,12 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     } else if (mode == 2) {
         P->off_bp = o; o = align_up(o + sizeof(int32_t) * (size_t)nab, 256);
     }
-    if (mode != 0 && P->big) {
+    if (mode != 0 && P->big && P->one_fsa && B >= 2 && !env_int("WF_NO_SHARED_BIG", 0)) {
+        P->shared = true;
+        const size_t groups = (size_t)(B + kNB - 1) / kNB;
+        P->off_big = o; o = align_up(o + 2 * acc_bytes * groups * (size_t)P->smax * kNB, 256);
+        P->off_Et = o; o = align_up(o + sizeof(float) * groups * (size_t)std::max(P->Tlong, 1) * (size_t)std::max(P->kmax, 1) * kNB, 256);
+    } else if (mode != 0 && P->big) {
         P->off_big = o; o = align_up(o + 2 * acc_bytes * (size_t)P->nstates, 256);
     }
     P->total = o;
@@ -2620,6 +2796,29 @@ int launch_big(const Plan& P, BigArgs a, int B, hipStream_t st) {
     hipLaunchKernelGGL((big_final_kernel<Acc, Sum, TROP>), dim3(B), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (side) HIP_TRY(hipStreamWaitEvent(st, side->join2, 0));
+    return WF_OK;
+}
+
+// big-graph forward sweep of a batch that shares one graph (Plan::shared)
+template <typename Acc, typename Sum, bool TROP>
+int launch_big_shared(const Plan& P, unsigned char* ws, const BigArgs& a, int B, hipStream_t st) {
+    BigSharedArgs q{};
+    q.blob = a.blob; q.utt = a.utt; q.lp = a.lp; q.strideB = a.strideB; q.strideT = a.strideT; q.E = a.E;
+    q.Et = (float*)(ws + P.off_Et); q.buf = ws + P.off_big; q.bp = a.bp;
+    q.B = B; q.Tlong = P.Tlong; q.S = P.smax; q.K = P.kmax; q.nlb = (P.smax + 255) / 256;
+    const int groups = (B + kNB - 1) / kNB;
+    if (P.Tlong > 0) hipLaunchKernelGGL(big_tr_kernel, dim3(P.Tlong, groups), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(big_init_shared_kernel<Acc>, dim3(std::min((P.smax * kNB + 255) / 256, 2048), groups), dim3(256), 0, st, q);
+    const dim3 grid(q.nlb + P.nheavy_in_max, groups);
+    for (int t = 0; t < P.Tlong; ++t) {
+        q.t = t;
+        hipLaunchKernelGGL((big_step_shared_kernel<Acc, Sum, TROP>), grid, dim3(256), 0, st, q);
+    }
+    BigArgs f = a;
+    f.buf = q.buf; f.alpha = nullptr; f.nstates = 0;
+    f.shared_S = P.smax; f.shared_par = P.Tlong & 1; f.shared_groups = groups;
+    hipLaunchKernelGGL((big_final_kernel<Acc, Sum, TROP>), dim3(B), dim3(256), 0, st, f);
+    HIP_TRY(hipGetLastError());
     return WF_OK;
 }
 
@@ -3054,7 +3253,8 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
             g.tot = tot; g.tot_double = 0;
             if (need_ab) { g.alpha = a.alpha; g.beta = a.beta; g.totd = a.totd; }
             else g.buf = ws + P.off_big;
-            rc = dbl ? launch_big<double, double, false>(P, g, B, st) : launch_big<double, float, false>(P, g, B, st);
+            if (!need_ab && P.shared) rc = dbl ? launch_big_shared<double, double, false>(P, ws, g, B, st) : launch_big_shared<double, float, false>(P, ws, g, B, st);
+            else rc = dbl ? launch_big<double, double, false>(P, g, B, st) : launch_big<double, float, false>(P, g, B, st);
         } else if (rc_.ok) rc = launch_sweep_quad<M_TOT_LOG>(rc_, a, B, st);
         else if (need_ab) rc = dbl ? launch_sweep<double, double, M_FB>(c, a, B, st) : launch_sweep<double, float, M_FB>(c, a, B, st);
         else rc = dbl ? launch_sweep<double, double, M_TOT_LOG>(c, a, B, st) : launch_sweep<double, float, M_TOT_LOG>(c, a, B, st);
@@ -3181,6 +3381,10 @@ extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, cons
         BigArgs g{};
         g.blob = a.blob; g.utt = a.utt; g.lp = log_probs; g.strideB = strideB; g.strideT = strideT; g.E = a.E;
         g.buf = ws + P.off_big; g.tot = tot; g.tot_double = a.tot_double;
+        if (P.shared) {
+            if (flags & WF_TROPICAL) return dbl ? launch_big_shared<double, double, true>(P, ws, g, B, st) : launch_big_shared<float, float, true>(P, ws, g, B, st);
+            return dbl ? launch_big_shared<double, double, false>(P, ws, g, B, st) : launch_big_shared<double, float, false>(P, ws, g, B, st);
+        }
         if (flags & WF_TROPICAL) return dbl ? launch_big<double, double, true>(P, g, B, st) : launch_big<float, float, true>(P, g, B, st);
         return dbl ? launch_big<double, double, false>(P, g, B, st) : launch_big<double, float, false>(P, g, B, st);
     }
@@ -3224,7 +3428,8 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
         BigArgs g{};
         g.blob = a.blob; g.utt = a.utt; g.lp = log_probs; g.strideB = strideB; g.strideT = strideT; g.E = a.E;
         g.buf = ws + P.off_big; g.tot = best_score; g.tot_double = 0; g.bp = a.bp; g.fin_arc = a.fin_arc;
-        rc = dbl ? launch_big<double, double, true>(P, g, B, st) : launch_big<float, float, true>(P, g, B, st);
+        if (P.shared) rc = dbl ? launch_big_shared<double, double, true>(P, ws, g, B, st) : launch_big_shared<float, float, true>(P, ws, g, B, st);
+        else rc = dbl ? launch_big<double, double, true>(P, g, B, st) : launch_big<float, float, true>(P, g, B, st);
     } else if (rc_.ok) rc = launch_sweep_quad<M_VITERBI>(rc_, a, B, st);
     else rc = dbl ? launch_sweep<double, double, M_VITERBI>(c, a, B, st) : launch_sweep<float, float, M_VITERBI>(c, a, B, st);
     if (rc) return rc;
