@@ -1886,7 +1886,34 @@ __global__ void __launch_bounds__(256) big_step_shared_kernel(BigSharedArgs p) {
         if (s >= S) return;
         const int a0 = off[s], a1 = off[s + 1];
         if (a1 - a0 > WF_HEAVY_DEG) return;
-        for (int a = a0; a < a1; ++a) push_arc(a);
+        // four arcs per round: their descriptor loads, then their alpha / emission gathers, are in flight together
+        // (one arc at a time is three dependent memory round trips per arc, and a lane has only ~3 arcs to hide them with)
+        for (int ab = a0; ab < a1; ab += 4) {
+            int sj[4], cj[4], idj[4];
+            float wj[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int a = min(ab + i, a1 - 1);
+                sj[i] = src[a]; cj[i] = col[a]; wj[i] = w[a]; idj[i] = TROP ? aid[a] : 0;
+            }
+            Acc c[4][kNB];
+            float e[4][kNB];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                load8<Acc>(cur + (int64_t)sj[i] * kNB, c[i]);
+                load8<float>(et + (int64_t)cj[i] * kNB, e[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (ab + i >= a1) break;
+#pragma unroll
+                for (int j = 0; j < kNB; ++j) {
+                    const Acc v = c[i][j] + (Acc)(wj[i] + e[i][j]);
+                    if (TROP) max_push(m[j], barc[j], v, idj[i]);
+                    else lse_push(m[j], sm[j], v);
+                }
+            }
+        }
         finish(s);
     } else {
         const int h = blockIdx.x - p.nlb;
