@@ -284,7 +284,13 @@ def main():
         ach = kb[dom] / (kt[dom] * 1e-3) / 1e9
         default_wl = (args.workload == "cfg3_ctc_bpe5k_num" and args.batch == 32 and args.frames == 500
                       and not args.ragged)
-        out["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom) if kt["check"] >= 0 else dom + "_kernel",
+        if default_wl:
+            kname = KERNEL_NAMES.get(dom, dom)
+        elif wl.S_mean > 4096 and kt["check"] >= 0:      # large denominators (cfg4): DESIGN.md section 4
+            kname = {"sweep": "sweep_linbig_kernel", "post": "post_big_kernel"}.get(dom, KERNEL_NAMES.get(dom, dom))
+        else:
+            kname = dom + " (kernel picked by graph size: DESIGN.md section 4)"
+        out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, default_wl),
                            "avg_launch_ms": kt[dom], "algorithmic_bytes_per_launch": kb[dom],

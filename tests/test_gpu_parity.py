@@ -244,16 +244,27 @@ def test_full_size_mmictc_denominator_properties(oracle_lib):
                                         use_double=True, nthreads=2)
     np.testing.assert_allclose(loss[:2], -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(grad[:2], grad_d, atol=GRAD_ATOL)
-    # the same sweep with the arcs re-read from memory in every frame (no register copy), the LDS-staged
-    # gradient kernel, and the per-frame-launch sweep: same arithmetic in the same order / same tolerances
-    l2, g2 = _with_env({"WF_NO_ARC_CACHE": "1"}, lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none"))
-    assert np.array_equal(loss, l2) and np.array_equal(grad, g2)
-    l3, g3 = _with_env({"WF_POST_BIG_MIN_S": "1000000"}, lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none"))
-    np.testing.assert_allclose(l3, loss, rtol=1e-6)
-    np.testing.assert_allclose(g3, grad, atol=1e-5)
-    l4, g4 = _with_env({"WF_BIG_MIN_S": "1000"}, lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none"))
-    np.testing.assert_allclose(l4, loss, rtol=1e-6)
-    np.testing.assert_allclose(g4, grad, atol=1e-5)
+    # default: probability-domain sweep_linbig_kernel.  The other implementations on the same batch: the
+    # log-semiring sweep with this thread's arcs in registers / re-read from memory in every frame (same
+    # arithmetic in the same order: bit-identical), the LDS-staged gradient kernel, the per-frame-launch sweep,
+    # and the linear sweep with every utterance sent through the check -> fallback path
+    run = lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none")
+    lg, gg = _with_env({"WF_NO_LINBIG_SWEEP": "1"}, run)
+    np.testing.assert_allclose(lg, loss, rtol=1e-6)
+    np.testing.assert_allclose(gg, grad, atol=2e-5)
+    np.testing.assert_allclose(lg[:2], -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(gg[:2], grad_d, atol=GRAD_ATOL)
+    l2, g2 = _with_env({"WF_NO_LINBIG_SWEEP": "1", "WF_NO_ARC_CACHE": "1"}, run)
+    assert np.array_equal(lg, l2) and np.array_equal(gg, g2)
+    l3, g3 = _with_env({"WF_NO_LINBIG_SWEEP": "1", "WF_POST_BIG_MIN_S": "1000000"}, run)
+    np.testing.assert_allclose(l3, lg, rtol=1e-6)
+    np.testing.assert_allclose(g3, gg, atol=1e-5)
+    l4, g4 = _with_env({"WF_BIG_MIN_S": "1000"}, run)
+    np.testing.assert_allclose(l4, lg, rtol=1e-6)
+    np.testing.assert_allclose(g4, gg, atol=1e-5)
+    l5, g5 = _with_env({"WF_FORCE_FALLBACK": "1"}, run)
+    np.testing.assert_allclose(l5, lg, rtol=1e-6)
+    np.testing.assert_allclose(g5, gg, atol=1e-5)
 
 
 # ---- every sweep implementation behind wf_fb_logsum, on the same inputs ----------------------------
@@ -266,6 +277,8 @@ SWEEP_PATHS = {
     "log_generic": {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "1"},
     "band_then_fallback": {"WF_FORCE_FALLBACK": "1"},
     "lin_then_fallback": {"WF_NO_BAND_SWEEP": "1", "WF_FORCE_FALLBACK": "1"},
+    "linbig": {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "2"},       # sweep_linbig_kernel (large denominators)
+    "linbig_then_fallback": {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "2", "WF_FORCE_FALLBACK": "1"},
 }
 
 

@@ -1209,6 +1209,248 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Linear-domain sweep for graphs of up to kLBSlot * 1024 states whose arcs do not fit the LDS (the BPE-5k
+// denominators of cfg4: S = 10 002, A = 30 002, a hub state with fan-in 15 001).  One workgroup of 1024 lanes
+// per (utterance, direction); a lane owns the states tid + i * 1024 in every frame and keeps their first two arcs
+// in registers (every light state of the 11 topologies has <= 2-3 arcs), as it does its slice of the hub's arc
+// list: nothing of the graph is re-read.  "Weights elided" graphs only (every arc weight 0, all training
+// topologies), so a frame step is one fp64 FMA per arc on alpha_t[src] and P_t[col], both in the LDS:
+//  * the state vector ping-pongs between two **fp32** LDS buffers (two fp64 ones would be the whole LDS at
+//    S = 10 002), steered to 2^kLBBias every frame from the exponent maximum of the previous row; sums are formed
+//    in fp64 and the rows that leave for the workspace are the unrounded fp64 sums times 2^(kLinBias - kLBBias), i.e.
+//    exactly the rows sweep_lin_kernel would store.  A state more than ~2^-226 below its row's maximum flushes to
+//    zero; like every underflow of the linear sweeps this is caught by the row check (fallback), not assumed away.
+//  * the fp32 emission row of the NEXT frame is loaded (coalesced, from gather_lin_kernel's P32 rows) into
+//    registers at the top of a step and stored to the LDS behind the step's first barrier: no step waits for memory.
+// Two barriers per frame (the hub's partial sums meet at the first).  Shifts: group size 1, lag 0 in
+// lin_shift_index terms; tot2 / ctot2 and the row check / fallback are those of sweep_lin_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kLBSlot = 10, kLBDeg = 2, kLBHeavy = 64, kLBHub = 16;
+constexpr int kLBBias = 100;   // fp32 LDS copy of a row: maximum steered to 2^kLBBias
+
+__global__ void __launch_bounds__(kMaxThreads) sweep_linbig_kernel(SweepArgs p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int u = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int fsa = uni((int)U[WF_U_FSA]), T = uni((int)U[WF_U_T]);
+    const int32_t* blob = p.blob;
+    const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
+    const int S = uni(I[WF_I_S]), A = uni(I[WF_I_A]), K = uni(I[WF_I_K]);
+    if (T < uni(I[WF_I_MINLEN])) {   // structurally infeasible: no sweep needed
+        if (dir == 0 && tid == 0) {
+            ((float*)p.tot)[u] = -INFINITY;
+            p.totd[u] = (double)-INFINITY;
+            p.tot2[u] = (double)-INFINITY;
+            p.ctot2[u] = 0.0;
+        }
+        return;
+    }
+    const int spad = p.smax + 4;
+    double* red = (double*)smem;                  // [kLBHeavy][16] per-wave partial sums of the heavy states
+    int* rexp = (int*)(red + kLBHeavy * 16);      // [2][16] per-wave maxima of the exponent field, by step parity
+    float* buf0 = (float*)(rexp + 32);            // [spad] x 2: slot S holds 0 (the source of padding arcs)
+    float* buf1 = buf0 + spad;
+    float* pl = buf1 + spad;                      // [kpad] emission probabilities of the current frame
+
+    const int32_t* g_off = blob + uni(I[dir ? WF_I_OUT_OFF : WF_I_IN_OFF]);
+    const int32_t* g_oth = blob + uni(I[dir ? WF_I_OUT_DST : WF_I_IN_SRC]);
+    const int32_t* g_col = blob + uni(I[dir ? WF_I_OUT_COL : WF_I_IN_COL]);
+    const int nheavy = uni(I[dir ? WF_I_NHEAVY_OUT : WF_I_NHEAVY_IN]);
+    const int32_t* heavy = blob + uni(I[dir ? WF_I_HEAVY_OUT : WF_I_HEAVY_IN]);
+
+    // ---- this lane's states: first kLBDeg arcs in registers (padding: source S = 0.0, column 0)
+    unsigned mine = 0, more = 0;
+    int pk[kLBSlot][kLBDeg];
+#pragma unroll
+    for (int i = 0; i < kLBSlot; ++i) {
+        const int sidx = tid + i * nt;
+        int a0 = 0, deg = -1;
+        if (sidx < S) { a0 = g_off[sidx]; deg = g_off[sidx + 1] - a0; }
+        if (deg > WF_HEAVY_DEG) deg = -1;
+        if (deg >= 0) mine |= 1u << i;
+        if (deg > kLBDeg) more |= 1u << i;
+#pragma unroll
+        for (int d = 0; d < kLBDeg; ++d) pk[i][d] = d < deg ? (g_oth[a0 + d] | (g_col[a0 + d] << 16)) : S;
+    }
+    // ---- the first heavy state's arcs, a strided slice per lane (hubs beyond kLBHub * 1024 arcs: the rest is streamed)
+    int hpk[kLBHub];
+    {
+        int h0 = 0, h1 = 0;
+        if (nheavy > 0) { h0 = g_off[heavy[0]]; h1 = g_off[heavy[0] + 1]; }
+#pragma unroll
+        for (int j = 0; j < kLBHub; ++j) {
+            const int a = h0 + tid + j * nt;
+            hpk[j] = a < h1 ? (g_oth[a] | (g_col[a] << 16)) : S;
+        }
+    }
+
+    const float* pbase = (const float*)p.P + uni(U[WF_U_P]);   // fp32 rows (gather_lin_kernel, P32)
+    int64_t ppitch = uni((int)U[WF_U_PP]);
+    if (A == 0 || T == 0) { pbase = (const float*)U; ppitch = 0; }
+    double* arena = (double*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
+    double* goff = (dir ? p.boff : p.aoff) + uni(U[WF_U_OFFS]);
+
+    // ---- initial vector (stored unscaled, shift 0) and its exponent maximum
+    {
+        const float* fb = (const float*)(blob + uni(I[WF_I_FINB_LOG]));
+        int emax = 0;
+        for (int s = tid; s < S; s += nt) {
+            const double v = dir ? exp((double)fb[s]) : (s == 0 ? 1.0 : 0.0);
+            buf0[s] = (float)v;
+            arena[(int64_t)(dir ? T : 0) * S + s] = v;
+            emax = max(emax, f64_exp_field(v));
+        }
+        if (tid == 0) { buf0[S] = 0.f; buf1[S] = 0.f; goff[0] = 0.0; }
+        if (T > 0) {   // emission row of the first step
+            const float* prow0 = pbase + (int64_t)(dir ? T - 1 : 0) * ppitch;
+            for (int k = tid; k < K; k += nt) pl[k] = prow0[k];
+        }
+        emax = wave_max_i(emax);
+        if (tid < 32) rexp[tid] = 0;
+        __syncthreads();
+        if (lane == 0) rexp[wave] = emax;
+        __syncthreads();
+    }
+    // the LDS copy of row r is the true scaled row times 2^-lds_less: 0 for the initial row, kLinBias - kLBBias after
+    double cum = 0.0;   // cumulative shift of the rows in the workspace
+    int lds_less = 0;
+    float* cur = buf0;
+    float* nxt = buf1;
+    for (int step = 0; step < T; ++step) {
+        const int f = dir ? T - 1 - step : step;
+        double* srow = arena + (int64_t)(dir ? f : f + 1) * S;
+        int* rx_in = rexp + (step & 1) * 16;
+        int* rx_out = rexp + ((step + 1) & 1) * 16;
+        // the descriptors are loop-invariant: without this, hipcc hoists the two LDS byte addresses of every arc out of
+        // the frame loop (72 more live registers) and spills
+#pragma unroll
+        for (int i = 0; i < kLBSlot; ++i)
+#pragma unroll
+            for (int d = 0; d < kLBDeg; ++d) asm volatile("" : "+v"(pk[i][d]));
+#pragma unroll
+        for (int j = 0; j < kLBHub; ++j) asm volatile("" : "+v"(hpk[j]));
+        // next step's emission row: coalesced loads now, into the LDS behind this step's first barrier.  Uniform base
+        // + lane offset (no per-slot address registers); slots past K read on into the arena, which is padded by
+        // kLBSlot * 1024 floats for this (make_plan), and are never stored
+        float pn[kLBSlot];
+        {
+            const int fn = step + 1 < T ? (dir ? f - 1 : f + 1) : f;
+            const float* prown = pbase + (int64_t)fn * ppitch;
+#pragma unroll
+            for (int i = 0; i < kLBSlot; ++i) pn[i] = (prown + i * nt)[(unsigned)tid];
+        }
+        // rescale decided from the previous row's exponent maximum (exponent fields of the LDS-scale values)
+        int sh;
+        {
+            int4 m4 = ((const int4*)rx_in)[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                const int4 r = ((const int4*)rx_in)[i];
+                m4.x = max(m4.x, r.x); m4.y = max(m4.y, r.y); m4.z = max(m4.z, r.z); m4.w = max(m4.w, r.w);
+            }
+            const int emax = max(max(m4.x, m4.y), max(m4.z, m4.w));
+            sh = emax > 0 ? (1023 + kLBBias) - emax : 0;   // brings the LDS-scale row to 2^kLBBias
+        }
+        // workspace row = LDS-scale row * 2^(kLinBias - kLBBias); its cumulative shift:
+        cum += (double)(sh + (kLinBias - kLBBias) - lds_less);
+        lds_less = kLinBias - kLBBias;
+        if (tid == 0) goff[step + 1] = cum;
+        if (lane == 0) rx_out[wave] = 0;
+        int emine = 0;
+        // ---- this lane's light states
+#pragma unroll
+        for (int i = 0; i < kLBSlot; ++i) {
+            double v = (double)cur[pk[i][0] & 0xffff] * (double)pl[(pk[i][0] >> 16) & 0xffff];
+#pragma unroll
+            for (int d = 1; d < kLBDeg; ++d) v = fma((double)cur[pk[i][d] & 0xffff], (double)pl[(pk[i][d] >> 16) & 0xffff], v);
+            if ((more >> i) & 1) {
+                const int32_t* go = g_off + i * nt;
+                for (int a = go[(unsigned)tid] + kLBDeg; a < go[(unsigned)tid + 1]; ++a) v = fma((double)cur[g_oth[a]], (double)pl[g_col[a]], v);
+            }
+            if ((mine >> i) & 1) {
+                v = ldexp(v, sh);
+                (nxt + i * nt)[(unsigned)tid] = (float)v;
+                (srow + i * nt)[(unsigned)tid] = ldexp(v, kLinBias - kLBBias);
+                emine = max(emine, f64_exp_field(v));
+            }
+        }
+        // ---- heavy states: every lane a strided slice of the arc list
+        for (int hi = 0; hi < nheavy; ++hi) {
+            const int hs = heavy[hi];
+            const int a0 = g_off[hs], a1 = g_off[hs + 1];
+            double part = 0.0;
+            int ab = a0 + tid;
+            if (hi == 0) {   // descriptors in registers
+#pragma unroll
+                for (int j = 0; j < kLBHub; ++j) part = fma((double)cur[hpk[j] & 0xffff], (double)pl[(hpk[j] >> 16) & 0xffff], part);
+                ab += kLBHub * nt;
+            }
+            for (; ab < a1; ab += nt * 4) {
+                int so[4], co[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int a = ab + j * nt;
+                    const bool on = a < a1;
+                    const int ac = on ? a : a1 - 1;
+                    so[j] = on ? g_oth[ac] : S;
+                    co[j] = g_col[ac];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part = fma((double)cur[so[j]], (double)pl[co[j]], part);
+            }
+            part = wave_sum_d(part);
+            if (lane == 0) red[hi * 16 + wave] = part;
+        }
+        __syncthreads();   // partial sums complete; every read of pl is done
+#pragma unroll
+        for (int i = 0; i < kLBSlot; ++i)
+            if (tid < K - i * nt) (pl + i * nt)[(unsigned)tid] = pn[i];
+        if (tid < nheavy) {
+            double v = red[tid * 16];
+            for (int w = 1; w < nw; ++w) v += red[tid * 16 + w];
+            v = ldexp(v, sh);
+            const int hs = heavy[tid];
+            nxt[hs] = (float)v;
+            srow[hs] = ldexp(v, kLinBias - kLBBias);
+            emine = max(emine, f64_exp_field(v));
+        }
+        emine = wave_max_i(emine);
+        if (lane == 0) rx_out[wave] = emine;
+        __syncthreads();
+        float* t_ = cur; cur = nxt; nxt = t_;
+    }
+
+    // ---- forward workgroup: total score = log(sum over final arcs) - shifts + sum_t c_t
+    if (dir == 0) {
+        const int NF = I[WF_I_NF];
+        const int32_t* fsrc = blob + I[WF_I_FIN_SRC];
+        const float* fw = (const float*)(blob + I[WF_I_FIN_W]);
+        double part = 0.0, csum = 0.0;
+        for (int i = tid; i < NF; i += nt) part = fma((double)cur[fsrc[i]], exp((double)fw[i]), part);
+        const double* crow = p.cmax + U[WF_U_ROW0];
+        for (int t = tid; t < T; t += nt) csum += crow[t];
+        part = wave_sum_d(part);
+        csum = wave_sum_d(csum);
+        if (lane == 0) { red[wave] = part; red[16 + wave] = csum; }
+        __syncthreads();
+        if (tid == 0) {
+            double fsum = 0.0, ct = 0.0;
+            for (int i = 0; i < nw; ++i) { fsum += red[i]; ct += red[16 + i]; }
+            const double ctot2 = ct * kLog2eD;
+            const bool dead = !(fsum > 0.0);
+            const double tot2 = dead ? (double)-INFINITY : log2(fsum) - (cum - (double)lds_less) + ctot2;
+            const double tot = dead ? (double)-INFINITY : tot2 * kLn2;
+            p.tot2[u] = tot2;
+            p.ctot2[u] = ctot2;
+            p.totd[u] = tot;
+            ((float*)p.tot)[u] = (float)tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Banded wave sweep: the linear-domain forward-backward recursion of a numerator graph with NO LDS
 // round trip of the state vector and NO barrier on the critical path.
 //
@@ -2037,6 +2279,7 @@ struct GatherLinArgs {
     double* P;
     double* cmax;
     int32_t* flag;
+    float* P32;   // != null (sweep_linbig_kernel): the probabilities are written here as fp32 (same offsets and pitch), not to P
 };
 
 __global__ void __launch_bounds__(64) gather_lin_kernel(GatherLinArgs p) {
@@ -2060,8 +2303,26 @@ __global__ void __launch_bounds__(64) gather_lin_kernel(GatherLinArgs p) {
     for (int k = lane + 64 * kGV; k < K; k += 64) m = fmaxf(m, row[direct ? k : labels[k]]);
     m = wave_max(m);
     if (!(m > -INFINITY)) m = 0.f;   // every label impossible in this frame: P = 0
-    double* prow = p.P + U[WF_U_P] + (int64_t)t * U[WF_U_PP];
     float* erow = p.E + U[WF_U_E] + (int64_t)t * K;
+    if (p.P32) {   // fp32 rows: ratios below 2^-126 of the frame's best label flush to 0 (the row check catches what that breaks)
+        float* prow = p.P32 + U[WF_U_P] + (int64_t)t * U[WF_U_PP];
+#pragma unroll
+        for (int i = 0; i < kGV; ++i) {
+            const int k = lane + 64 * i;
+            if (k < K) {
+                prow[k] = __builtin_amdgcn_exp2f((v[i] - m) * kLog2e);
+                if (!direct) erow[k] = v[i];
+            }
+        }
+        for (int k = lane + 64 * kGV; k < K; k += 64) {
+            const float x = row[direct ? k : labels[k]];
+            prow[k] = __builtin_amdgcn_exp2f((x - m) * kLog2e);
+            if (!direct) erow[k] = x;
+        }
+        if (lane == 0) p.cmax[U[WF_U_ROW0] + t] = (double)m;
+        return;
+    }
+    double* prow = p.P + U[WF_U_P] + (int64_t)t * U[WF_U_PP];
 #pragma unroll
     for (int i = 0; i < kGV; ++i) {
         const int k = lane + 64 * i;
@@ -2312,8 +2573,9 @@ __global__ void __launch_bounds__(256) post_kernel(PostArgs p) {
     }
 }
 
-// Gradient rows of graphs whose alpha / beta rows do not fit the LDS (log-domain fp64 rows, as the big-graph
-// sweep leaves them): no staging, alpha_t[src] + beta_{t+1}[dst] gathered from memory in fp64 per arc.
+// Gradient rows of graphs whose alpha / beta rows do not fit the LDS, or are long enough that staging them costs
+// more than gathering: no staging, alpha_t[src] and beta_{t+1}[dst] gathered from memory in fp64 per arc (log-domain
+// rows of the big-graph / log-semiring sweeps, or the scaled-probability rows of sweep_linbig_kernel: log2 per arc).
 // Columns with up to kPostHeavy arcs: one lane each; heavier ones: summed by a whole wavefront over
 // coalesced slices of the column-sorted arc arrays (fixed reduction tree: bit-stable, no atomics).
 // grid = (Tmax, num_seqs), 256 threads.
@@ -2349,7 +2611,17 @@ __global__ void __launch_bounds__(256) post_big_kernel(PostArgs p) {
         else if (K < V) zero_span(grow + K, V - K, tid, 256);
         if (!direct) __syncthreads();
     }
+    // row format: scaled probabilities + shifts (linear-domain sweep) or natural-log scores (log-semiring sweep / fallback)
+    const bool lin = p.lin && !p.flag[u];
+    const double cst = lin ? lin_post_const(p, U, u, t, T) : 0.0;
     auto post = [&](int a, float e) {
+        if (lin) {
+            double ea, eb;
+            float fa, fb;
+            log2_split(arow[lsrc[a]], ea, fa);
+            log2_split(brow[ldst[a]], eb, fb);
+            return __builtin_amdgcn_exp2f((float)(ea + eb + cst) + (fa + fb) + (lw[a] + e) * kLog2e);   // exp2(-inf) = 0 for dead states
+        }
         const double x = arow[lsrc[a]] + brow[ldst[a]] - tot;   // -inf for dead states
         return __builtin_amdgcn_exp2f(((float)x + (lw[a] + e)) * kLog2e);
     };
@@ -2576,6 +2848,7 @@ struct Plan {
     bool big = false;       // graphs too large for the LDS sweeps: one launch per frame
     bool shared = false;    // ... and the whole batch uses one graph (forward-only calls): kNB utterances per lane
     bool one_fsa = true;
+    bool linbig = false;    // lin, by sweep_linbig_kernel (emission probabilities kept as fp32)
     size_t off_big = 0, off_Et = 0;
     int64_t nstates = 0;
     int nheavy_in_max = 0, nheavy_out_max = 0;
@@ -2603,6 +2876,7 @@ int env_int(const char* name, int dflt);
 constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where nothing else fits, until measured otherwise
 struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; };
 BandSel band_config(const Plan& P);
+bool linbig_config(const Plan& P);
 
 // dbl_exact: WF_DOUBLE_ACC (k2 use_double_scores=True): exp/log in fp64 too, log-semiring sweep only
 int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V,
@@ -2676,11 +2950,12 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         if (P->big && pruned)
             return wf_fail(WF_EUNSUPPORTED, "output_beam pruning is not available for graphs beyond the LDS-resident sweeps (%d states)", P->smax);
         P->pruned = pruned;
-        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok);
+        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok || linbig_config(*P));
         P->off_ctot2 = o; o = align_up(o + sizeof(double) * B, 256);
         P->off_flag = o; o = align_up(o + sizeof(int32_t) * B, 256);
+        P->linbig = P->lin && !band_config(*P).ok && !lin_config(*P).ok;
         if (P->lin) {
-            P->off_P = o; o = align_up(o + sizeof(double) * (size_t)nP, 256);
+            P->off_P = o; o = align_up(o + (P->linbig ? sizeof(float) * ((size_t)nP + kLBSlot * kMaxThreads) : sizeof(double) * (size_t)nP), 256);
             P->off_cmax = o; o = align_up(o + sizeof(double) * (size_t)std::max<int64_t>(row0, 1), 256);
         }
         P->off_alpha = o; o = align_up(o + acc_bytes * (size_t)nab, 256);
@@ -2933,6 +3208,34 @@ RegCfg lin_config(const Plan& P) {
 // frames per rescale group = ring depth of the kernel variant launch_sweep_lin() picks
 int lin_group(const RegCfg& c) { return c.threads <= 256 ? 8 : 4; }
 
+// linear-domain sweep for graphs whose arcs do not fit the LDS (sweep_linbig_kernel): weights-elided graphs of up to
+// kLBSlot * 1024 states with at most kLBHeavy heavy states, when neither the banded nor the lane-per-state sweep applies
+size_t linbig_lds(const Plan& P) { return (size_t)kLBHeavy * 16 * 8 + 32 * 4 + 2 * ((size_t)align_up(P.smax, 4) + 4) * 4 + align_up(P.kmax, 4) * 4; }
+bool linbig_config(const Plan& P) {
+    if (env_int("WF_NO_LIN_SWEEP", 0) == 1 || env_int("WF_NO_LINBIG_SWEEP", 0)) return false;   // test hooks, read per call (WF_NO_LIN_SWEEP=2: only the lane-per-state kernel is off)
+    if (band_config(P).ok || lin_config(P).ok) return false;
+    return P.band_we && P.smax <= kLBSlot * kMaxThreads && P.kmax <= kLBSlot * kMaxThreads && P.hmax <= kLBHeavy &&
+           linbig_lds(P) <= kLdsBudget;
+}
+
+// rescale bookkeeping of the linear-domain sweep that a call uses: frames per group and lag (lin_shift_index)
+void lin_grp_lag(const Plan& P, int* grp, int* lag) {
+    const BandSel bs = band_config(P);
+    if (bs.ok) { *grp = bs.grp; *lag = 0; }
+    else if (lin_config(P).ok) { *grp = lin_group(lin_config(P)); *lag = 1; }
+    else { *grp = 1; *lag = 0; }   // sweep_linbig_kernel
+}
+
+int launch_sweep_linbig(const Plan& P, SweepArgs a, int B, hipStream_t st) {
+    a.smax = (int)align_up(P.smax, 4);
+    const size_t lds = linbig_lds(P);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)sweep_linbig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(sweep_linbig_kernel, dim3(B * 2), dim3(kMaxThreads), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
 // banded wave sweep: every graph of the call is banded and fits one wavefront; picks the instantiation
 BandSel band_config(const Plan& P) {
     BandSel b;
@@ -3075,7 +3378,7 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
     if (P.lin) {
         GatherLinArgs g{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), lp, strideB, strideT,
                         (float*)(ws + P.off_E), (double*)(ws + P.off_P), (double*)(ws + P.off_cmax),
-                        (int32_t*)(ws + P.off_flag)};
+                        (int32_t*)(ws + P.off_flag), P.linbig ? (float*)(ws + P.off_P) : nullptr};
         hipLaunchKernelGGL(gather_lin_kernel, dim3(std::max(P.Tlong, 1), P.B), dim3(64), 0, st, g);
         HIP_TRY(hipGetLastError());
         return WF_OK;
@@ -3095,9 +3398,10 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
                 float* grad, bool skip_zero, hipStream_t st) {
     PostArgs q{};
     {
-        const BandSel bs = band_config(P);
-        q.lin = !P.lin ? 0 : (bs.ok ? bs.grp : lin_group(lin_config(P)));
-        q.lag = bs.ok ? 0 : 1;
+        int grp = 0, lag = 0;
+        lin_grp_lag(P, &grp, &lag);
+        q.lin = P.lin ? grp : 0;
+        q.lag = lag;
     }
     q.ctot2 = (const double*)(ws + P.off_ctot2); q.cmax = (const double*)(ws + P.off_cmax);
     q.flag = (const int32_t*)(ws + P.off_flag);
@@ -3128,8 +3432,8 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     }
     // rows beyond the LDS, or long enough that staging them costs more than gathering per arc (measured on cfg4's
     // denominators, S = 10 002: 2.4 ms against 3.9 ms): gather from memory.  Log-domain, unpruned rows only.
-    if (lds > kLdsBudget || (!P.lin && !P.pruned && P.smax >= env_int("WF_POST_BIG_MIN_S", 4096))) {
-        if (P.lin || P.pruned) return wf_fail(WF_EUNSUPPORTED, "internal: post_big_kernel needs log-domain, unpruned rows");
+    if (lds > kLdsBudget || ((!P.lin || P.linbig) && !P.pruned && P.smax >= env_int("WF_POST_BIG_MIN_S", 4096))) {
+        if (P.pruned) return wf_fail(WF_EUNSUPPORTED, "internal: post_big_kernel needs unpruned rows");
         hipLaunchKernelGGL(post_big_kernel, dim3(Tmax, num_seqs), dim3(256), 0, st, q);
         HIP_TRY(hipGetLastError());
         return WF_OK;
@@ -3240,11 +3544,13 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     if (P.lin) {
         // linear-domain sweep, then the row identity check and the log-semiring re-run of whatever failed it
         const BandSel bs = band_config(P);
-        rc = bs.ok ? launch_sweep_band(bs, a, B, st) : launch_sweep_lin(lin_config(P), a, B, st);
+        int lgrp = 0, llag = 0;
+        lin_grp_lag(P, &lgrp, &llag);
+        rc = bs.ok ? launch_sweep_band(bs, a, B, st) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
         CheckArgs k{a.blob, a.utt, (const double*)a.alpha, (const double*)a.beta, a.aoff, a.boff, a.tot2, a.ctot2,
-                    (int32_t*)(ws + P.off_flag), bs.ok ? bs.grp : lin_group(lin_config(P)), bs.ok ? 0 : 1,
+                    (int32_t*)(ws + P.off_flag), lgrp, llag,
                     env_int("WF_FORCE_FALLBACK", 0)};
         hipLaunchKernelGGL(check_kernel, dim3(P.Tlong + 1, B), dim3(64), 0, st, k);
         HIP_TRY(hipGetLastError());
@@ -3371,8 +3677,8 @@ extern "C" int wf_state_posteriors(const void* graph_host, const void* graph_dev
     a.tot2 = (const double*)(ws + P.off_tot2); a.ctot2 = (const double*)(ws + P.off_ctot2);
     a.totd = (const double*)(ws + P.off_totd); a.flag = (const int32_t*)(ws + P.off_flag);
     a.lin = P.lin ? 1 : 0;
-    a.grp = !P.lin ? 1 : (bs.ok ? bs.grp : lin_group(lin_config(P)));
-    a.lag = bs.ok ? 0 : 1;
+    lin_grp_lag(P, &a.grp, &a.lag);
+    if (!P.lin) a.grp = 1;
     a.out = out; a.strideB = out_strideB; a.strideT = out_strideT; a.Smax = Smax; a.Tmax = Tmax;
     hipLaunchKernelGGL(state_post_kernel, dim3(std::max(Tmax, 1), B), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
