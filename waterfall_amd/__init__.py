@@ -11,10 +11,11 @@ from .graph import GraphLoss, graphloss, tot_scores, best_path, set_output_beam_
 from .compile import linear_fsa, remove_epsilon_and_add_self_loops, arc_sort, compose, compile_ctc_k2_graphs
 from . import manual_ctc
 from . import dist
+from .lang import Lang, write_lang_dir
 from .topology import build_topology, topology_text, Topology, TOPOLOGIES
 
 __all__ = [
-    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path", "set_output_beam_mode", "manual_ctc", "dist",
+    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path", "set_output_beam_mode", "manual_ctc", "dist", "Lang", "write_lang_dir",
     "linear_fsa", "remove_epsilon_and_add_self_loops", "arc_sort", "compose", "compile_ctc_k2_graphs",
     "build_topology", "topology_text", "Topology", "TOPOLOGIES",
 ]

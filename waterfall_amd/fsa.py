@@ -69,7 +69,7 @@ class Fsa:
             if not f:
                 continue
             if len(f) <= 2:
-                finals.append((int(f[0]), -(float(f[1]) if len(f) == 2 else 0.0)))
+                finals.append((int(f[0]), 0.0 - (float(f[1]) if len(f) == 2 else 0.0)))   # 0.0 - w: never -0.0
                 max_state = max(max_state, int(f[0]))
                 continue
             s, d = int(f[0]), int(f[1])
@@ -79,7 +79,7 @@ class Fsa:
             else:
                 ol = sym_out[f[3]] if sym_out is not None else int(f[3])
             w = float(f[2 + n_lab]) if len(f) > 2 + n_lab else 0.0
-            arcs.append((s, d, il, -w))
+            arcs.append((s, d, il, 0.0 - w))
             aux.append(ol)
             max_state = max(max_state, s, d)
         sf = max_state + 1
