@@ -663,3 +663,31 @@ def test_big_graph_shared_by_the_batch_two_groups_all_semirings():
     sc2, arcs2, trop2, logt2, log642 = _with_env({"WF_NO_SHARED_BIG": "1"}, run)
     assert np.array_equal(sc, sc2) and np.array_equal(arcs, arcs2) and np.array_equal(trop, trop2)
     assert np.array_equal(logt, logt2) and np.array_equal(log64, log642)
+
+
+def test_lattice_analysis_call_shapes_on_a_decoding_graph():
+    # utils/lattice_analysis.py:120-135 with the same names; a word-labelled decoding graph (aux = word ids)
+    g, lp, segs = _big_case(12_001, B=2, T=33, seed=21)
+    rng = np.random.default_rng(3)
+    g["aux"] = np.where(g["label"] >= 0, np.where(rng.random(g["label"].size) < 0.2, rng.integers(1, 50, g["label"].size), 0),
+                        -1).astype(np.int32)
+    arcs_ = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
+    TLG = wf.Fsa(arcs_, g["aux"], [0, arcs_.shape[0]], [g["num_states"]])
+    x = torch.from_numpy(lp).to(DEV)
+    lens = torch.tensor([33, 20])
+    lattice = wf.get_lattice(x, lens, TLG, search_beam=20, output_beam=8)
+    tot = lattice.get_tot_scores(True, True).cpu().numpy()
+    best = lattice.get_tot_scores(True, False).cpu().numpy()
+    one_best = wf.one_best_decoding(lattice)
+    words = wf.get_aux_labels(one_best)
+    for i, T in enumerate([33, 20]):
+        s, path = o.viterbi(g, lp[i], T, dtype=np.float64)
+        np.testing.assert_allclose(best[i], s, rtol=1e-12)
+        np.testing.assert_allclose(tot[i], o.forward(g, lp[i], T)[1], rtol=1e-9)
+        s32, path32 = o.viterbi(g, lp[i], T)
+        assert one_best.labels[i] == [int(g["label"][a]) for a in path32] and one_best.labels[i][-1] == -1
+        assert words[i] == [int(g["aux"][a]) for a in path32 if g["aux"][a] > 0]
+        assert one_best.get_tot_scores(True, False)[i].item() == float(s32)
+    dense = wf.DenseFsaVec(x, torch.tensor([[0, 0, 33], [1, 0, 20]], dtype=torch.int32))
+    again = wf.intersect_dense(TLG, dense, 10).get_tot_scores(True, True).cpu().numpy()
+    assert np.array_equal(again, tot)

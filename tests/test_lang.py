@@ -69,5 +69,5 @@ def test_cfg1_yesno_on_the_gpu_numerator_and_denominator(tmp_path):
     tg = lang.topo.as_oracle_graphs()[0]
     wd, gd = o.graphloss([tg] * 8, lp.numpy(), segs, None, "none")
     np.testing.assert_allclose(num.detach().cpu().numpy(), wn, rtol=1e-4)
-    np.testing.assert_allclose(den.detach().cpu().numpy(), wd, rtol=1e-4)
+    np.testing.assert_allclose(den.detach().cpu().numpy(), wd, rtol=1e-4, atol=1e-4)   # the CTC topology accepts every path: tot = 0
     np.testing.assert_allclose(x.grad.cpu().numpy(), gn - gd, atol=1e-3)

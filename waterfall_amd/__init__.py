@@ -12,10 +12,13 @@ from .compile import linear_fsa, remove_epsilon_and_add_self_loops, arc_sort, co
 from . import manual_ctc
 from . import dist
 from .lang import Lang, write_lang_dir
+from .decode import (DenseLattice, OneBest, get_lattice, intersect_dense, one_best_decoding, shortest_path,
+                     get_aux_labels)
 from .topology import build_topology, topology_text, Topology, TOPOLOGIES
 
 __all__ = [
-    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path", "set_output_beam_mode", "manual_ctc", "dist", "Lang", "write_lang_dir",
+    "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "tot_scores", "best_path", "set_output_beam_mode", "manual_ctc", "dist", "Lang", "write_lang_dir", "DenseLattice", "OneBest", "get_lattice", "intersect_dense",
+    "one_best_decoding", "shortest_path", "get_aux_labels",
     "linear_fsa", "remove_epsilon_and_add_self_loops", "arc_sort", "compose", "compile_ctc_k2_graphs",
     "build_topology", "topology_text", "Topology", "TOPOLOGIES",
 ]
