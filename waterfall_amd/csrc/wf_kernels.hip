@@ -2339,6 +2339,47 @@ __global__ void __launch_bounds__(64) gather_lin_kernel(GatherLinArgs p) {
     if (lane == 0) p.cmax[U[WF_U_ROW0] + t] = (double)m;
 }
 
+// Rows of at most 128 columns (numerators: K ~ L + 1): kGFR frames per wavefront, the gathers of all of them in
+// flight together.  One frame per wave is a chain of three dependent memory round trips (utterance table -> label ->
+// log-prob) on 16 000 waves that need two residency rounds; this is one round with the chains overlapped.
+constexpr int kGFR = 4;
+
+__global__ void __launch_bounds__(64) gather_lin_small_kernel(GatherLinArgs p) {
+    const int lane = threadIdx.x;
+    const int t0 = blockIdx.x * kGFR, u = blockIdx.y;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    if (t0 == 0 && lane == 0) p.flag[u] = 0;
+    const int T = (int)U[WF_U_T];
+    if (t0 >= T) return;
+    const int K = (int)U[WF_U_K], direct = (int)U[WF_U_DIRECT];
+    const int32_t* labels = p.blob + U[WF_U_LABELS];
+    const float* row0 = p.lp + U[WF_U_SEQ] * p.strideB + (U[WF_U_START] + t0) * p.strideT;
+    const int k0 = lane, k1 = lane + 64;
+    const int c0 = k0 < K ? (direct ? k0 : labels[k0]) : 0;
+    const int c1 = k1 < K ? (direct ? k1 : labels[k1]) : 0;
+    float v0[kGFR], v1[kGFR];
+#pragma unroll
+    for (int r = 0; r < kGFR; ++r) {
+        const float* row = row0 + (int64_t)min(r, T - 1 - t0) * p.strideT;   // frames past T re-read the last one (not stored)
+        v0[r] = row[c0];
+        v1[r] = row[c1];
+    }
+    const int64_t pp = U[WF_U_PP];
+    double* prow = p.P + U[WF_U_P] + (int64_t)t0 * pp;
+    float* erow = p.E + U[WF_U_E] + (int64_t)t0 * K;
+    double* crow = p.cmax + U[WF_U_ROW0] + t0;
+#pragma unroll
+    for (int r = 0; r < kGFR; ++r) {
+        if (t0 + r >= T) break;
+        const float a = k0 < K ? v0[r] : -INFINITY, b = k1 < K ? v1[r] : -INFINITY;
+        float m = wave_max(fmaxf(a, b));
+        if (!(m > -INFINITY)) m = 0.f;   // every label impossible in this frame: P = 0
+        if (k0 < K) { prow[r * pp + k0] = exp((double)a - (double)m); if (!direct) erow[r * K + k0] = a; }
+        if (k1 < K) { prow[r * pp + k1] = exp((double)b - (double)m); if (!direct) erow[r * K + k1] = b; }
+        if (lane == 0) crow[r] = (double)m;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // posterior / gradient rows
 // ------------------------------------------------------------------------------------------
@@ -3379,7 +3420,10 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
         GatherLinArgs g{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), lp, strideB, strideT,
                         (float*)(ws + P.off_E), (double*)(ws + P.off_P), (double*)(ws + P.off_cmax),
                         (int32_t*)(ws + P.off_flag), P.linbig ? (float*)(ws + P.off_P) : nullptr};
-        hipLaunchKernelGGL(gather_lin_kernel, dim3(std::max(P.Tlong, 1), P.B), dim3(64), 0, st, g);
+        if (!P.linbig && P.kmax <= 128 && !env_int("WF_NO_GATHER_SMALL", 0))
+            hipLaunchKernelGGL(gather_lin_small_kernel, dim3((std::max(P.Tlong, 1) + kGFR - 1) / kGFR, P.B), dim3(64), 0, st, g);
+        else
+            hipLaunchKernelGGL(gather_lin_kernel, dim3(std::max(P.Tlong, 1), P.B), dim3(64), 0, st, g);
         HIP_TRY(hipGetLastError());
         return WF_OK;
     }
