@@ -1467,7 +1467,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_linbig_kernel(SweepArgs p) 
 // previous chunk's last row) and the row check / fallback are as for sweep_lin_kernel.
 // Measured (cfg3, MI355X): 190 cycles per frame step against 440 for sweep_lin_kernel.
 // ------------------------------------------------------------------------------------------
-constexpr int kBandKP = 192;   // row pitch of the staged emission rows; a banded graph uses < kBandKP label columns
+constexpr int kBandKP = 256;   // row pitch of the staged emission rows; a banded graph uses < kBandKP label columns (two 128-column pieces per row)
 constexpr int kBandC = 16;     // frames per chunk
 
 // wave_shr:1 of a double: lane i receives lane i-1's value, lane 0 receives 0 (bound_ctrl)
