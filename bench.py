@@ -35,9 +35,9 @@ import waterfall_amd as wf  # noqa: E402
 from waterfall_amd import _lib  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-KERNEL_NAMES = {"gather": "gather_lin_kernel", "sweep": "sweep_band_kernel", "post": "post_small_kernel",
+KERNEL_NAMES = {"gather": "gather_lin_small_kernel", "sweep": "sweep_band_kernel", "post": "post_small_kernel",
                 "zero": "zero_flat_kernel", "check": "check_kernel"}
-PMC_FILE = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def pmc_traffic(kernel, is_default_workload):
@@ -297,7 +297,7 @@ def main():
                            "note": "dominant kernel by duration. The alpha/beta sweep is dependency-latency bound (T "
                                    "sequential frame steps; kernels.sweep.us_per_frame_step is its figure of merit); the "
                                    "only bandwidth-bound kernel is the gradient zero-fill, which runs beside the sweep on "
-                                   "a side stream (kernels.zero). traffic: profiles/r01c_pmc_traffic.json"}
+                                   "a side stream (kernels.zero). traffic: profiles/r01d_pmc_traffic.json"}
         out["kernels"] = {k: {"avg_ms": kt[k], "algorithmic_bytes": kb[k],
                               "GBps": kb[k] / (kt[k] * 1e-3) / 1e9 if kt[k] > 0 else None} for k in kt}
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
