@@ -146,19 +146,37 @@ class Workload:
 
 
 def time_steps(wl, steps, warmup, dist, stream, fused_buf):
+    bufs = [fused_buf, fused_buf.clone()]
+    works = [None, None]
+    count = [0]
+
     def one():
         wl.step(stream)
         if dist is not None:
-            # single fused all-reduce: [loss_sum, n_frames, n_infeasible]
-            wf.dist.fused_loss_stats(wl.tot, wl.frames, out=fused_buf)
+            # single fused all-reduce per step: [loss_sum, n_frames, n_infeasible], started asynchronously on one of two
+            # buffers so that it overlaps the next step's sweeps (logging data: nothing on the data path waits for it)
+            j = count[0] & 1
+            count[0] += 1
+            if works[j] is not None:
+                works[j].wait()
+            _, works[j] = wf.dist.fused_loss_stats(wl.tot, wl.frames, out=bufs[j], async_op=True)
+
+    def drain():
+        for j in (0, 1):
+            if works[j] is not None:
+                works[j].wait()
+                works[j] = None
+
     for _ in range(warmup):
         one()
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
+    drain()          # every step's all-reduce is inside the timed region
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -245,7 +263,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        backend = os.environ.get("WF_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
+            local = local % max(torch.cuda.device_count(), 1)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -302,7 +325,7 @@ def main():
                               "GBps": kb[k] / (kt[k] * 1e-3) / 1e9 if kt[k] > 0 else None} for k in kt}
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
         out["path_GBps_survey_8d"] = kb["path_survey_8d"] / (ms_step * 1e-3) / 1e9
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl)
         if args.others and world == 1:
             others = {}

@@ -174,6 +174,11 @@ int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt
                const int32_t* seg, int32_t B, int32_t Tmax, uint32_t flags, float* best_score,
                int32_t* best_arcs, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- multi-GPU: the buffer of the one fused all-reduce per step (the reference gets these numbers
+ * from Lightning's DDP reductions around graph.py:66-76).  out[0] = -(sum of the finite tot[i]), out[1] = n_frames,
+ * out[2] = number of infeasible utterances (tot = -inf); device pointers, one small launch on `stream`.            */
+int wf_loss_stats(const float* tot, int32_t B, float n_frames, float* out, void* stream);
+
 /* ---- measurement aid (no counterpart in the reference) ------------------------------------------
  * wf_timing_enable(1): the following wf_fb_logsum / wf_fb_backward calls of this host thread record
  * HIP events on the caller's stream around each kernel; wf_timing_read() waits for them and

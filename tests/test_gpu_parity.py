@@ -691,3 +691,16 @@ def test_lattice_analysis_call_shapes_on_a_decoding_graph():
     dense = wf.DenseFsaVec(x, torch.tensor([[0, 0, 33], [1, 0, 20]], dtype=torch.int32))
     again = wf.intersect_dense(TLG, dense, 10).get_tot_scores(True, True).cpu().numpy()
     assert np.array_equal(again, tot)
+
+
+def test_loss_stats_kernel_matches_the_elementwise_formula():
+    from waterfall_amd.dist import fused_loss_stats
+    rng = np.random.default_rng(4)
+    for B in (1, 7, 300, 1000):
+        t = rng.normal(-50, 20, size=B).astype(np.float32)
+        t[rng.random(B) < 0.1] = -np.inf
+        x = torch.from_numpy(t).to(DEV)
+        out = fused_loss_stats(x, 1234).cpu().numpy()
+        ok = np.isfinite(t)
+        np.testing.assert_allclose(out[0], -t[ok].astype(np.float64).sum(), rtol=1e-5)
+        assert out[1] == 1234 and out[2] == (~ok).sum()

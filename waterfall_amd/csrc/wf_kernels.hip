@@ -3047,6 +3047,7 @@ int tm_record(int i, hipStream_t st) {
 struct Side {
     hipStream_t stream = nullptr, stream2 = nullptr;   // zero-fill | backward direction of the big-graph sweep
     hipEvent_t fork = nullptr, join = nullptr, fork2 = nullptr, join2 = nullptr;
+    bool fill_attr = false;
 };
 thread_local Side g_side[16];
 int side_get(Side** out) {
@@ -3554,10 +3555,9 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
                 // would compete with the chain wave for issue slots (measured: the co-resident sweep workgroups
                 // ran 1.6-3.8x longer and set the kernel's duration).
                 constexpr int kFillLds = 84 * 1024;
-                static bool fill_attr = false;
-                if (!fill_attr) {
+                if (!side->fill_attr) {   // once per device (the attribute belongs to the device's copy of the kernel)
                     HIP_TRY(hipFuncSetAttribute((const void*)zero_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFillLds));
-                    fill_attr = true;
+                    side->fill_attr = true;
                 }
                 hipLaunchKernelGGL(zero_flat_kernel, dim3(std::max(blocks, 1)), dim3(256), kFillLds, side->stream,
                                    (float4*)grad, n4, grad + n4 * 4, (int)(n - n4 * 4));
@@ -3648,6 +3648,33 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
         if ((rc = tm_record(4, st))) return rc;
         g_tm.have_post = g_tm.on;
     }
+    return WF_OK;
+}
+
+// [-sum of the finite tot, n_frames, number of infeasible utterances] in one launch (the buffer of the one fused
+// all-reduce per step); B <= any, one workgroup
+__global__ void __launch_bounds__(256) loss_stats_kernel(const float* tot, int B, float n_frames, float* out) {
+    __shared__ float rs[4], rn[4];
+    float s = 0.f, n = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float v = tot[i];
+        if (v > -INFINITY && v < INFINITY) s -= v; else n += 1.f;
+    }
+    s = wave_sum(s);
+    n = wave_sum(n);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rn[threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+        out[1] = n_frames;
+        out[2] = (rn[0] + rn[1]) + (rn[2] + rn[3]);
+    }
+}
+
+extern "C" int wf_loss_stats(const float* tot, int32_t B, float n_frames, float* out, void* stream) {
+    if (!tot || !out || B < 0) return wf_fail(WF_EINVAL, "wf_loss_stats: bad argument");
+    hipLaunchKernelGGL(loss_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tot, B, n_frames, out);
+    HIP_TRY(hipGetLastError());
     return WF_OK;
 }
 

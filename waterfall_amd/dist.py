@@ -35,13 +35,16 @@ def shard_batch(lengths, world, rank, mode="round_robin"):
     raise ValueError(f"unknown shard mode {mode!r}")
 
 
-def fused_loss_stats(tot, n_frames, group=None, grad=None, out=None):
+def fused_loss_stats(tot, n_frames, group=None, grad=None, out=None, async_op=False):
     """One all-reduce(SUM) of [loss_sum, n_frames, n_infeasible (, sum_{b,t} grad[b,t,:])] over the job.
 
     tot: [B_local] total scores of this rank's shard (-inf = infeasible utterance: counted, not summed, as the
     reference's loss would otherwise be inf for the whole job).  n_frames: number of frames of the shard.
     grad: optional [B_local, T, V] gradient whose per-label column sums are appended (V floats).
     out: optional preallocated float32 buffer of the right size on tot's device (no allocation in the step).
+    async_op: start the all-reduce without making the current stream wait for it; returns (buffer, work) and the
+    caller calls work.wait() before it reads or reuses the buffer (bench.py alternates two buffers, so the collective
+    of step i overlaps the sweeps of step i + 1: the statistics are logging data, not on the data path).
     Returns the reduced buffer; `dict(zip(STATS_FIELDS, buf[:3].tolist()))` names the scalars.
     """
     import torch.distributed as dist
@@ -50,12 +53,22 @@ def fused_loss_stats(tot, n_frames, group=None, grad=None, out=None):
         out = torch.empty(3 + V, dtype=torch.float32, device=tot.device)
     elif out.numel() != 3 + V or out.dtype != torch.float32:
         raise ValueError(f"out must be float32 with {3 + V} elements")
-    ok = torch.isfinite(tot)
-    out[0] = -torch.where(ok, tot, torch.zeros_like(tot)).sum()
-    out[1] = float(n_frames)
-    out[2] = (~ok).sum()
+    if tot.device.type == "cuda" and tot.dtype == torch.float32 and tot.is_contiguous():
+        # one launch instead of eight elementwise ones (they cost as much as a quarter of a cfg3 step)
+        import ctypes as C
+        from . import _lib
+        with torch.cuda.device(tot.device):
+            _lib.check(_lib.lib().wf_loss_stats(C.c_void_p(tot.data_ptr()), tot.numel(), float(n_frames),
+                                                C.c_void_p(out.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream(tot.device).cuda_stream)))
+    else:
+        ok = torch.isfinite(tot)
+        out[0] = -torch.where(ok, tot, torch.zeros_like(tot)).sum()
+        out[1] = float(n_frames)
+        out[2] = (~ok).sum()
     if V:
         out[3:] = grad.reshape(-1, V).sum(0)
+    work = None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(out, group=group)
-    return out
+        work = dist.all_reduce(out, group=group, async_op=async_op)
+    return (out, work) if async_op else out
