@@ -1,0 +1,50 @@
+"""Randomised parity run (GPU): random topology / sizes / ragged lengths / sweep path against the numpy oracle.
+usage: python tools/fuzz_gpu.py [cases] [seed]   (test infrastructure: imports oracle/)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import util  # noqa: E402
+from oracle import dwfst_oracle as o  # noqa: E402
+import waterfall_amd as wf  # noqa: E402
+
+PATHS = [{}, {"WF_NO_BAND_SWEEP": "1"}, {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "1"}, {"WF_FORCE_FALLBACK": "1"},
+         {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "2"}, {"WF_BIG_MIN_S": "1"}, {"WF_BIG_MIN_S": "1", "WF_POST_BIG_MIN_S": "1"},
+         {"WF_NO_GATHER_SMALL": "1"}]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+topos = sorted(wf.TOPOLOGIES)
+bad = 0
+for case in range(n):
+    topo = topos[rng.integers(len(topos))]
+    den = bool(rng.integers(2))
+    B, T, L, P = int(rng.integers(1, 10)), int(rng.integers(1, 90)), int(rng.integers(0, 13)), int(rng.integers(2, 13))
+    env = PATHS[rng.integers(len(PATHS))]
+    c = util.random_case(int(rng.integers(1 << 30)), topo, B=B, T=T, L=L, P=P, den=den, ragged=bool(rng.integers(2)))
+    for k in list(os.environ):
+        if k.startswith("WF_"):
+            del os.environ[k]
+    os.environ.update(env)
+    x = torch.from_numpy(c["lp"]).cuda().requires_grad_(True)
+    dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
+    loss = wf.graphloss(c["fsa"], dense, reduction="none")
+    fin = torch.isfinite(loss)
+    torch.where(fin, loss, torch.zeros_like(loss)).sum().backward()
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    got, g = loss.detach().cpu().numpy(), x.grad.cpu().numpy()
+    ok = np.allclose(got, want, rtol=1e-4, atol=1e-4) and np.allclose(g, np.where(np.isfinite(wgrad), wgrad, 0), atol=1e-3) \
+        and np.all(np.isfinite(g))
+    best = wf.best_path(c["fsa"], dense)
+    for i, gr in enumerate(c["ographs"]):
+        s, path = o.viterbi(gr, c["lp"][i], int(c["segs"][i, 2]))
+        if best["scores"][i].item() != s and not (np.isinf(s) and np.isinf(best["scores"][i].item())):
+            ok = False
+    if not ok:
+        bad += 1
+        print("MISMATCH", case, topo, den, B, T, L, P, env, np.abs(got - want).max(), flush=True)
+print(f"{n} cases, {bad} mismatches", flush=True)
+sys.exit(1 if bad else 0)
