@@ -265,6 +265,12 @@ def test_full_size_mmictc_denominator_properties(oracle_lib):
     l5, g5 = _with_env({"WF_FORCE_FALLBACK": "1"}, run)
     np.testing.assert_allclose(l5, lg, rtol=1e-6)
     np.testing.assert_allclose(g5, gg, atol=1e-5)
+    # forward only (torch.no_grad() denominators): planned as both linear sweeps + row check without the posterior
+    # kernel; the same totals as the gradient call, and as the log-semiring forward sweep
+    fwd = lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none", need_grad=False)[0]
+    assert np.array_equal(fwd(), loss)
+    np.testing.assert_allclose(_with_env({"WF_NO_FWD_VIA_FB": "1"}, fwd), loss, rtol=1e-6)
+    np.testing.assert_allclose(_with_env({"WF_FORCE_FALLBACK": "1"}, fwd), loss, rtol=1e-6)
 
 
 # ---- every sweep implementation behind wf_fb_logsum, on the same inputs ----------------------------

@@ -1,5 +1,5 @@
 """Randomised parity run (GPU): random topology / sizes / ragged lengths / sweep path against the numpy oracle.
-usage: python tools/fuzz_gpu.py [cases] [seed]   (test infrastructure: imports oracle/)"""
+usage: python tools/fuzz_gpu.py [cases] [seed] [big]   (test infrastructure: imports oracle/)"""
 import os
 import sys
 
@@ -22,7 +22,8 @@ bad = 0
 for case in range(n):
     topo = topos[rng.integers(len(topos))]
     den = bool(rng.integers(2))
-    B, T, L, P = int(rng.integers(1, 10)), int(rng.integers(1, 90)), int(rng.integers(0, 13)), int(rng.integers(2, 13))
+    big = len(sys.argv) > 3   # third argument: larger cases (more kernel instantiations)
+    B, T, L, P = int(rng.integers(1, 10)), int(rng.integers(1, 300 if big else 90)), int(rng.integers(0, 90 if big else 13)), int(rng.integers(2, 45 if big else 13))
     env = PATHS[rng.integers(len(PATHS))]
     c = util.random_case(int(rng.integers(1 << 30)), topo, B=B, T=T, L=L, P=P, den=den, ragged=bool(rng.integers(2)))
     for k in list(os.environ):

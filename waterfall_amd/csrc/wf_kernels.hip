@@ -3361,15 +3361,32 @@ int launch_sweep_quad(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
 
 }  // namespace
 
+// Plan of a wf_fb_logsum call.  rows: the caller wants alpha / beta kept (gradient, WF_KEEP_AB) or pruning needs them.
+// A forward-only call (torch.no_grad() denominators, conformer.py:413) on a graph that sweep_linbig_kernel handles
+// is planned as a forward-backward call without the posterior kernel (*fwd_via_fb): both linear-domain sweeps + the
+// row check (which needs beta) take 3.8 ms on cfg4's denominators, the log-semiring forward sweep alone 7.5 ms.
+int plan_fb(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V, int num_seqs, bool rows,
+            bool dbl, bool pruned, Plan* P, bool* fwd_via_fb) {
+    *fwd_via_fb = false;
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, rows ? 0 : 1, P, dbl, pruned);
+    if (rc || rows || dbl || P->smax < 4096 || P->big || env_int("WF_NO_FWD_VIA_FB", 0)) return rc;
+    Plan P0;
+    if (make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P0, false, false) == WF_OK && P0.linbig) {
+        *P = P0;
+        *fwd_via_fb = true;
+    }
+    return WF_OK;
+}
+
 extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
                                      int32_t B, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes) {
     if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
     Plan P;
-    const size_t ab = 8;  // log semiring: alpha/beta are always kept in fp64
     int maxseq = 0;
     if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, (need_grad || (flags & (WF_KEEP_AB | WF_PRUNED))) ? 0 : 1, &P,
-                       (flags & WF_DOUBLE_ACC) != 0, (flags & WF_PRUNED) != 0);
+    bool fwd_via_fb = false;
+    int rc = plan_fb(graph_host, utt2fsa, seg, B, V, maxseq, need_grad || (flags & (WF_KEEP_AB | WF_PRUNED)),
+                     (flags & WF_DOUBLE_ACC) != 0, (flags & WF_PRUNED) != 0, &P, &fwd_via_fb);
     if (rc) return rc;
     *bytes = P.total + 256;
     return WF_OK;
@@ -3513,7 +3530,8 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     const bool need_ab = grad || (flags & WF_KEEP_AB);
     const size_t ab = 8;
     Plan P;
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, (need_ab || pruned) ? 0 : 1, &P, dbl, pruned);
+    bool fwd_via_fb = false;
+    int rc = plan_fb(graph_host, utt2fsa, seg, B, V, num_seqs, need_ab || pruned, dbl, pruned, &P, &fwd_via_fb);
     if (rc) return rc;
     for (int i = 0; i < B; ++i)
         if (seg[3 * i + 1] + seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d exceeds Tmax=%d", i, Tmax);
