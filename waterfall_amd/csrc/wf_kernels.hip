@@ -2409,6 +2409,7 @@ struct PostArgs {
     int lin;        // != 0: the call used sweep_lin_kernel (rows are scaled probabilities, fp64, + per-group
                     // shifts); the value is the sweep's frames per rescale group
     int lag;        // see lin_shift_index
+    int prof;       // measurement aid (WF_POST_PROFILE=1): one wave of post_small_kernel prints its cycle counts
     const float* mA;   // output_beam pruning: tropical alpha^ / beta^ rows and the per-utterance threshold (null: no pruning)
     const float* mB;
     const float* thr;
@@ -2773,8 +2774,12 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
         ga = aoffs[lin ? lin_shift_index(t - 1, p.lin, p.lag) : 0];
         gb = boffs[lin ? lin_shift_index(T - 2 - t, p.lin, p.lag) : 0];
     };
+    const unsigned long long c_start = __builtin_amdgcn_s_memtime();
     fetch(t0);
+    unsigned long long c_f[kPostFR + 1];
+    int nfr = 0;
     for (int t = t0; t < t1; ++t) {
+        if (p.prof) c_f[nfr++] = __builtin_amdgcn_s_memtime();
         // ---- this frame's values -> LDS (log2 domain, both vectors centred)
         double a_ref, b_ref;
         float xs;
@@ -2802,13 +2807,16 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
             if (s < K) le[s] = ev[i] * kLog2e;
         }
         if (t + 1 < t1) fetch(t + 1);   // next frame's loads fly while this frame is reduced
-        __syncthreads();
+        // One wavefront: its LDS operations execute in order, so no s_barrier is needed -- and __syncthreads() would
+        // first drain vmcnt, i.e. wait for the prefetch just issued and for the previous frame's scattered stores
+        // (measured: ~4 us of exposed memory latency per frame).  wave_barrier only pins the instruction order.
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < PSA; ++i) {
             const int a = lane + i * 64;
             if (a < A) lpost[a] = __builtin_amdgcn_exp2f(la[asrc[i]] + lb[adst[i]] + (aw[i] + le[acol[i]]));
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)(start + t) * p.strideT;
         // per-column sums in arc order (bit-stable)
 #pragma unroll
@@ -2829,7 +2837,12 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
                 if (lane == hl) grow[klab[i]] = gs * acc;
             }
         }
-        __syncthreads();   // la / lb / le / lpost are rewritten by the next frame
+        __builtin_amdgcn_wave_barrier();   // la / lb / le / lpost are rewritten by the next frame
+    }
+    if (p.prof && blockIdx.x == 60 && blockIdx.y == 5 && lane == 0) {
+        const unsigned long long c_end = __builtin_amdgcn_s_memtime();
+        printf("post_small: setup %llu, frames %llu %llu %llu, last+drain %llu cycles (100 MHz ticks x24)\n", c_f[0] - c_start,
+               nfr > 1 ? c_f[1] - c_f[0] : 0ull, nfr > 2 ? c_f[2] - c_f[1] : 0ull, nfr > 3 ? c_f[3] - c_f[2] : 0ull, c_end - c_f[nfr - 1]);
     }
 }
 
@@ -3465,6 +3478,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
         q.lin = P.lin ? grp : 0;
         q.lag = lag;
     }
+    q.prof = env_int("WF_POST_PROFILE", 0);
     q.ctot2 = (const double*)(ws + P.off_ctot2); q.cmax = (const double*)(ws + P.off_cmax);
     q.flag = (const int32_t*)(ws + P.off_flag);
     if (P.pruned) { q.mA = (const float*)(ws + P.off_mA); q.mB = (const float*)(ws + P.off_mB); q.thr = (const float*)(ws + P.off_thr); }
@@ -3487,6 +3501,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
         const int need = std::max(std::max((P.smax + 63) / 64, (P.kmax_compact + 63) / 64), (P.amax + 127) / 128);
         const dim3 grid((Tmax + kPostFR - 1) / kPostFR, num_seqs);
         if (need <= 2) hipLaunchKernelGGL(post_small_kernel<2>, grid, dim3(64), lds2, st, q);
+        else if (need <= 3) hipLaunchKernelGGL(post_small_kernel<3>, grid, dim3(64), lds2, st, q);   // cfg3: S ~ 130, A ~ 323 (the kernel is instruction-bound)
         else if (need <= 4) hipLaunchKernelGGL(post_small_kernel<4>, grid, dim3(64), lds2, st, q);
         else hipLaunchKernelGGL(post_small_kernel<8>, grid, dim3(64), lds2, st, q);
         HIP_TRY(hipGetLastError());
