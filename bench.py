@@ -49,6 +49,19 @@ def pmc_traffic(kernel, is_default_workload):
     k = json.load(open(PMC_FILE))["kernels"].get(KERNEL_NAMES.get(kernel, ""))
     return k["hbm_bytes_per_launch_fetch_doubled"] if k else None
 
+def rocprof_avg_us(kernel, is_default_workload):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/r01d_bench_cfg3_kernel_stats.txt), for comparison with the live HIP-event interval."""
+    path = os.path.join(ROOT, "profiles", "r01d_bench_cfg3_kernel_stats.txt")
+    name = KERNEL_NAMES.get(kernel, "")
+    if not is_default_workload or not name or not os.path.exists(path):
+        return None
+    for line in open(path):
+        if name in line:
+            return float(line.split()[2])
+    return None
+
+
 WORKLOADS = {
     # name: (topology, P, L, kind) -- BASELINE.md section 3
     "cfg3_ctc_bpe5k_num": dict(topo="ctc", P=5000, L=64, den=False,
@@ -317,10 +330,14 @@ def main():
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, default_wl),
                            "avg_launch_ms": kt[dom], "algorithmic_bytes_per_launch": kb[dom],
+                           "rocprof_avg_launch_us": rocprof_avg_us(dom, default_wl),
                            "note": "dominant kernel by duration. The alpha/beta sweep is dependency-latency bound (T "
                                    "sequential frame steps; kernels.sweep.us_per_frame_step is its figure of merit); the "
                                    "only bandwidth-bound kernel is the gradient zero-fill, which runs beside the sweep on "
-                                   "a side stream (kernels.zero). traffic: profiles/r01d_pmc_traffic.json"}
+                                   "a side stream (kernels.zero). avg_launch_ms is the HIP-event interval around the launch on its "
+                                   "stream (it includes the launch / event latency and, for the sweep, the fork of the fill: "
+                                   "~7 us more than the kernel's own duration in the committed rocprofv3 summary, "
+                                   "rocprof_avg_launch_us). traffic: profiles/r01d_pmc_traffic.json"}
         out["kernels"] = {k: {"avg_ms": kt[k], "algorithmic_bytes": kb[k],
                               "GBps": kb[k] / (kt[k] * 1e-3) / 1e9 if kt[k] > 0 else None} for k in kt}
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
