@@ -109,6 +109,18 @@ int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* topo_aux, i
                             int32_t* out_arcs, int32_t* out_aux, int64_t arc_capacity,
                             int32_t* out_arc_off, int32_t* out_num_states);
 
+/* The same for ARBITRARY epsilon-free right-hand graphs (one per utterance), e.g. the phone-level graph of a word
+ * sequence under a lexicon with alternative pronunciations and optional silence (datapipe.py:244-254: L_inv o words,
+ * inverted, epsilons removed, epsilon self-loops added, then k2.compose(topo, ., treat_epsilons_specially=False)).
+ * b_arcs int32 [.,4] = {src, dst, phone >= 1 | -1, fp32 score bits}, sorted by source state, label -1 arcs into the last
+ * state; b_aux: word ids (or NULL: the output aux label is the phone); b_arc_off[B+1], b_num_states[B].
+ * Output label = token, aux = b's aux, score = fp32 sum.  Same two-call protocol as wf_compose_linear_batch.          */
+int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs,
+                         int32_t topo_num_states, const int32_t* index, const int32_t* b_arcs, const int32_t* b_aux,
+                         const int32_t* b_arc_off, const int32_t* b_num_states, int32_t B,
+                         int32_t* out_arcs, int32_t* out_aux, int64_t arc_capacity,
+                         int32_t* out_arc_off, int32_t* out_num_states);
+
 /* ---- workspace ------------------------------------------------------------------------------
  * utt2fsa: host [B] FSA index used by utterance i, or NULL for the identity (B == G); a single
  * shared denominator topology (rnnp.py:91-92) is utt2fsa = {0,0,...}.

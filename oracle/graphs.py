@@ -90,6 +90,53 @@ def compose_topo_transcript(topo, phones):
     return make_graph(arcs, sf + 1, aux)
 
 
+def compose_topo_fsa(topo, b):
+    """compose(topo, b, treat_epsilons_specially=False) for an arbitrary epsilon-free right-hand acceptor / transducer
+    b (label = phone >= 1, aux = word id or 0, label -1 arcs into its last state) that carries an epsilon self-loop on
+    every state (k2.remove_epsilon_and_add_self_loops, datapipe.py:249-254).  Product states (q, r) in BFS order from
+    (0, 0); per product state the topology's arcs in order, and per topology arc with phone p the arcs of r labelled p
+    in b's order; topology arcs with phone 0 pair with the self-loop.  Output label = token, aux = b's aux (phone when
+    b has none), score = sum.  A product final arc needs a final arc on both sides."""
+    tout = [[] for _ in range(topo["num_states"])]
+    for a in range(topo["src"].size):
+        tout[int(topo["src"][a])].append(a)
+    bout = [[] for _ in range(b["num_states"])]
+    for a in range(b["src"].size):
+        bout[int(b["src"][a])].append(a)
+    baux = b.get("aux")
+    ids = {(0, 0): 0}
+    order = [(0, 0)]
+    q = deque([(0, 0)])
+    arcs, aux, fin = [], [], []
+    while q:
+        s, r = q.popleft()
+        for a in tout[s]:
+            lab, ph, d, w = int(topo["label"][a]), int(topo["aux"][a]), int(topo["dst"][a]), np.float32(topo["score"][a])
+            if lab < 0:
+                for e in bout[r]:
+                    if int(b["label"][e]) < 0:
+                        fin.append((ids[(s, r)], np.float32(w + np.float32(b["score"][e]))))
+                continue
+            if ph == 0:
+                nxt = [((d, r), w, 0)]
+            else:
+                nxt = [((d, int(b["dst"][e])), np.float32(w + np.float32(b["score"][e])),
+                        int(baux[e]) if baux is not None else ph) for e in bout[r] if int(b["label"][e]) == ph]
+            for ns, ww, ax in nxt:
+                if ns not in ids:
+                    ids[ns] = len(order)
+                    order.append(ns)
+                    q.append(ns)
+                arcs.append((ids[(s, r)], ids[ns], lab, float(ww)))
+                aux.append(ax)
+    sf = len(order)
+    # final arcs go to the end of their source state's arcs (as in compose_topo_transcript after make_graph's sort)
+    for s, w in fin:
+        arcs.append((s, sf, -1, float(w)))
+        aux.append(-1)
+    return make_graph(arcs, sf + 1, aux)
+
+
 FMIN = np.finfo(np.float32).min
 
 

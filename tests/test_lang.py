@@ -71,3 +71,93 @@ def test_cfg1_yesno_on_the_gpu_numerator_and_denominator(tmp_path):
     np.testing.assert_allclose(num.detach().cpu().numpy(), wn, rtol=1e-4)
     np.testing.assert_allclose(den.detach().cpu().numpy(), wd, rtol=1e-4, atol=1e-4)   # the CTC topology accepts every path: tot = 0
     np.testing.assert_allclose(x.grad.cpu().numpy(), gn - gd, atol=1e-3)
+
+
+# ---- word-level graphs: alternative pronunciations + optional silence (datapipe.py:244-254 via L_inv) --------------
+
+LEX_VARIANTS = YESNO_LEXICON + [("YES", ["Y", "E"]), ("O", ["O"])]
+
+
+def _accepted_strings(g, limit=200000):
+    """All label strings of an acyclic oracle graph."""
+    out_arcs = {}
+    for s, d, l in zip(g["src"], g["dst"], g["label"]):
+        out_arcs.setdefault(int(s), []).append((int(d), int(l)))
+    res, stack = set(), [(0, ())]
+    while stack:
+        s, pre = stack.pop()
+        for d, l in out_arcs.get(s, []):
+            if l < 0:
+                res.add(pre)
+            else:
+                stack.append((d, pre + (l,)))
+        assert len(res) < limit
+    return res
+
+
+def test_word_graphs_accept_exactly_the_lexicon_expansions(tmp_path):
+    d = wf.write_lang_dir(str(tmp_path), LEX_VARIANTS, YESNO_PHONES, "2state_sil")
+    lang = wf.Lang(d, load_topo=True)
+    P = lang.phone2idx
+    wids = [[lang.word2idx["YES"], lang.word2idx["NO"]]]
+    g = lang.word_graphs(wids, "<SIL>").as_oracle_graphs()[0]
+    want = set()
+    sil = [(), (P["<SIL>"],)]
+    for a in sil:
+        for yes in ((P["Y"], P["E"], P["S"]), (P["Y"], P["E"])):
+            for b in sil:
+                for c in sil:
+                    want.add(a + yes + b + (P["N"], P["O"]) + c)
+    assert _accepted_strings(g) == want
+    # word ids sit on the first arc of each pronunciation
+    words = sorted(int(x) for x in g["aux"] if x > 0)
+    assert words == sorted([lang.word2idx["YES"]] * 4 + [lang.word2idx["NO"]] * 2)
+    # weights: log(0.5) on silence arcs / where silence is skipped
+    gw = lang.word_graphs(wids, "<SIL>", 0.5).as_oracle_graphs()[0]
+    assert set(gw["score"].tolist()) == {0.0, float(np.float32(np.log(0.5)))}
+
+
+@pytest.mark.parametrize("topo", ["ctc", "2state", "2state_sil", "2state_sil3", "mmictc", "mmictc_noblk", "3state-skip-2"])
+def test_general_compose_equals_oracle_and_linear_case(tmp_path, topo):
+    from oracle import graphs as og
+    d = wf.write_lang_dir(str(tmp_path), LEX_VARIANTS, YESNO_PHONES, topo)
+    lang = wf.Lang(d, load_topo=True)
+    wids = [[lang.word2idx[w] for w in ws] for ws in (["YES", "NO"], ["O"], ["NO", "O", "YES"], [])]
+    tg = lang.topo.as_oracle_graphs()[0]
+    for sp in (None, 0.3):
+        bg = lang.word_graphs(wids, "<SIL>", sp)
+        g = lang.compile_training_graph(wids, optional_silence="<SIL>", sil_prob=sp)
+        for got, bo in zip(g.as_oracle_graphs(), bg.as_oracle_graphs()):
+            want = og.compose_topo_fsa(tg, bo)
+            assert got["num_states"] == want["num_states"]
+            for k in ("src", "dst", "label", "aux", "score"):
+                assert np.array_equal(got[k], want[k]), (topo, k)
+    pids = lang.get_pids_list_from_wids_list(wids[:3])
+    lin = wf.create_fsa_vec([wf.Fsa.from_arcs([(i, i + 1, p, 0.0) for i, p in enumerate(ps)] + [(len(ps), len(ps) + 1, -1, 0.0)],
+                                              len(ps) + 2, list(ps) + [-1]) for ps in pids])
+    a, b = wf.compose(lang.topo, lin), wf.compile_ctc_k2_graphs(lang.topo, pids)
+    assert np.array_equal(a.arcs, b.arcs) and np.array_equal(a.aux_labels, b.aux_labels)
+    assert np.array_equal(a.fsa_num_states, b.fsa_num_states)
+
+
+@pytest.mark.gpu
+def test_word_level_numerators_on_the_gpu(tmp_path):
+    d = wf.write_lang_dir(str(tmp_path), LEX_VARIANTS, YESNO_PHONES, "2state_sil")
+    lang = wf.Lang(d, load_topo=True)
+    rng = np.random.default_rng(11)
+    names = ["YES", "NO", "O"]
+    wids = [[lang.word2idx[names[x]] for x in rng.integers(0, 3, size=n)] for n in (6, 3, 9, 1)]
+    graphs = lang.compile_training_graph(wids, optional_silence="<SIL>", sil_prob=0.5)
+    B, T, V = 4, 70, lang.num_nn_output
+    gen = torch.Generator().manual_seed(3)
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=gen) * 2.0, -1)
+    segs = np.array([[0, 0, 70], [1, 0, 41], [2, 0, 66], [3, 0, 9]], dtype=np.int32)
+    x = lp.to(DEV).requires_grad_(True)
+    loss = wf.graphloss(graphs, wf.DenseFsaVec(x, torch.from_numpy(segs)), reduction="none")
+    loss.sum().backward()
+    want, wgrad = o.graphloss(graphs.as_oracle_graphs(), lp.numpy(), segs, None, "none")
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), want, rtol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), wgrad, atol=1e-3)
+    best = wf.best_path(graphs, wf.DenseFsaVec(x.detach(), torch.from_numpy(segs)))
+    # the aux labels along the best path spell the word sequence
+    assert best["aux_labels"] == wids

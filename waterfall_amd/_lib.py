@@ -42,6 +42,7 @@ _SIGS = {
     "wf_graph_prepare_bytes": (C.c_int, [C.POINTER(_GraphHost), C.POINTER(_sz)]),
     "wf_graph_prepare": (C.c_int, [C.POINTER(_GraphHost), _p, _sz]),
     "wf_compose_linear": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, C.POINTER(_i32), C.POINTER(_i32), _i32]),
+    "wf_compose_fsa_batch": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, C.c_int64, _p, _p]),
     "wf_loss_stats": (C.c_int, [_p, _i32, C.c_float, _p, _p]),
     "wf_topo_index_words": (C.c_int, [_i32, _i32, C.POINTER(C.c_int64)]),
     "wf_topo_index_build": (C.c_int, [_p, _p, _i32, _i32, _p]),

@@ -89,8 +89,10 @@ def compose(topo, b, treat_epsilons_specially=False):
     """
     if treat_epsilons_specially:
         raise NotImplementedError("the reference always composes with treat_epsilons_specially=False")
+    if isinstance(b, Fsa):
+        return _compose_graphs(topo, b)
     if not isinstance(b, LinearFsaVec) or not b.self_loops:
-        raise TypeError("compose expects remove_epsilon_and_add_self_loops(linear_fsa(...)) on the right")
+        raise TypeError("compose expects remove_epsilon_and_add_self_loops(linear_fsa(...)) or an epsilon-free Fsa vector on the right")
     lib = _lib.lib()
     tab = _topo_tables(topo)
     B = len(b.seqs)
@@ -111,6 +113,40 @@ def compose(topo, b, treat_epsilons_specially=False):
                                          ps.size if ps is not None else 0, flat.ctypes.data, off.ctypes.data, B,
                                          oa.ctypes.data, ox.ctypes.data, cap, arc_off.ctypes.data, ns.ctypes.data)
         if rc == -2 and arc_off[B] > cap:  # WF_ENOSPC: sizes were still reported
+            cap = int(arc_off[B])
+            continue
+        _lib.check(rc)
+        break
+    n = int(arc_off[B])
+    return Fsa(oa[:n], ox[:n], arc_off, ns[:B])
+
+
+def _compose_graphs(topo, b):
+    """compose(topo, b) for a vector of arbitrary epsilon-free phone graphs b (labels = phones >= 1, aux_labels = word
+    ids, one graph per utterance; the epsilon self-loops of remove_epsilon_and_add_self_loops are implied):
+    datapipe.py:249-254.  One native call (wf_compose_fsa_batch)."""
+    if b.utt2fsa is not None:
+        raise ValueError("compose: the right-hand side must hold one graph per utterance")
+    tab = _topo_tables(topo)
+    if tab["ctc_cross"]:
+        raise NotImplementedError("the factored large-table CTC topology composes with linear transcripts only")
+    lib = _lib.lib()
+    B = b.num_fsas
+    ba = np.ascontiguousarray(b.arcs, dtype=np.int32)
+    bx = np.ascontiguousarray(b.aux_labels, dtype=np.int32) if b.aux_labels is not None else None
+    boff = np.ascontiguousarray(b.fsa_arc_offsets, dtype=np.int32)
+    bns = np.ascontiguousarray(b.fsa_num_states, dtype=np.int32)
+    arc_off = np.zeros(B + 1, dtype=np.int32)
+    ns = np.zeros(max(B, 1), dtype=np.int32)
+    cap = 16 * int(ba.shape[0]) + 64
+    while True:
+        oa = np.empty((cap, 4), dtype=np.int32)
+        ox = np.empty(cap, dtype=np.int32)
+        rc = lib.wf_compose_fsa_batch(tab["arcs"].ctypes.data, tab["aux"].ctypes.data, tab["arcs"].shape[0], tab["num_states"],
+                                      tab["index"].ctypes.data, ba.ctypes.data, bx.ctypes.data if bx is not None else None,
+                                      boff.ctypes.data, bns.ctypes.data, B, oa.ctypes.data, ox.ctypes.data, cap,
+                                      arc_off.ctypes.data, ns.ctypes.data)
+        if rc == -2 and arc_off[B] > cap:
             cap = int(arc_off[B])
             continue
         _lib.check(rc)

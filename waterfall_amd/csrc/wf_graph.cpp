@@ -607,3 +607,110 @@ extern "C" int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* 
     if (!fits) return wf_fail(WF_ENOSPC, "wf_compose_linear_batch: arc capacity %lld < %lld", (long long)cap, (long long)w);
     return WF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// compose(topo, b, treat_epsilons_specially=False) for ARBITRARY epsilon-free right-hand graphs b (one per utterance):
+// the phone-level transcript graphs that a lexicon with alternative pronunciations / optional silence gives
+// (datapipe.py:244-254: L_inv o words, inverted, epsilons removed, epsilon self-loops added).  b: label = phone >= 1,
+// aux = word id (or NULL: the phone), label -1 arcs into its last state, arcs sorted by source state.  Product states
+// (q, r) in BFS order from (0, 0); per product state the topology's arcs in order and, per topology arc with phone p,
+// the arcs of r labelled p in b's order (phone 0 pairs with the implicit self-loop of r).  Output label = token,
+// aux = b's aux, score = the fp32 sum; a product final arc needs a final arc on both sides.
+// For a linear b the result is wf_compose_linear_batch's.
+// ------------------------------------------------------------------------------------------
+extern "C" int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA, int32_t nS,
+                                    const int32_t* index, const int32_t* b_arcs, const int32_t* b_aux,
+                                    const int32_t* b_arc_off, const int32_t* b_num_states, int32_t B,
+                                    int32_t* out_arcs, int32_t* out_aux, int64_t cap, int32_t* out_arc_off,
+                                    int32_t* out_num_states) {
+    if (!topo_arcs || !topo_aux || !index || nA < 1 || nS < 2 || B < 0 || !b_arc_off || !b_num_states || !out_arc_off || !out_num_states ||
+        (B > 0 && b_arc_off[B] > 0 && !b_arcs))
+        return wf_fail(WF_EINVAL, "wf_compose_fsa_batch: bad argument");
+    const int32_t* soff = index;
+    const int32_t* perm = index + nS + 1;
+    const int32_t* key = perm + nA;
+    PairMap id;
+    std::vector<int64_t> order;
+    std::vector<int32_t> arcs, aux, boff, cand, seen;
+    int64_t w = 0;
+    bool fits = out_arcs && out_aux;
+    out_arc_off[0] = 0;
+    auto fadd = [](int32_t xb, int32_t yb) { float x, y; memcpy(&x, &xb, 4); memcpy(&y, &yb, 4); x += y; int32_t r; memcpy(&r, &x, 4); return r; };
+    for (int b = 0; b < B; ++b) {
+        const int32_t* ba = b_arcs + 4 * (size_t)b_arc_off[b];
+        const int32_t* bx = b_aux ? b_aux + b_arc_off[b] : nullptr;
+        const int nb = b_arc_off[b + 1] - b_arc_off[b], R = b_num_states[b];
+        if (nb < 0 || R < 2) return wf_fail(WF_EINVAL, "wf_compose_fsa_batch: graph %d: needs a start and a final state", b);
+        boff.assign(R + 1, 0);
+        for (int e = 0; e < nb; ++e) {
+            const int s = ba[4 * e], d = ba[4 * e + 1], l = ba[4 * e + 2];
+            if (s < 0 || s >= R || d < 0 || d >= R) return wf_fail(WF_ERANGE, "wf_compose_fsa_batch: graph %d arc %d: state out of range", b, e);
+            if (e && s < ba[4 * (e - 1)]) return wf_fail(WF_EINVAL, "wf_compose_fsa_batch: graph %d: arcs must be sorted by source state", b);
+            if (l == 0 || l < -1) return wf_fail(WF_ERANGE, "wf_compose_fsa_batch: graph %d arc %d: label %d (epsilon-free graphs only)", b, e, l);
+            boff[s + 1]++;
+        }
+        for (int s = 0; s < R; ++s) boff[s + 1] += boff[s];
+        id.reset(8 * (size_t)(R + 2));
+        order.clear(); arcs.clear(); aux.clear();
+        auto pkey = [&](int q, int r) { return (int64_t)q * R + r; };
+        bool ins;
+        id.get(pkey(0, 0), 0, &ins);
+        order.push_back(pkey(0, 0));
+        auto emit = [&](int head, int q2, int r2, int tok, int32_t wbits, int ax) {
+            if (order.size() * 2 > id.k.size()) id.grow();
+            const int32_t nid = id.get(pkey(q2, r2), (int32_t)order.size(), &ins);
+            if (ins) order.push_back(pkey(q2, r2));
+            arcs.push_back(head); arcs.push_back(nid); arcs.push_back(tok); arcs.push_back(wbits);
+            aux.push_back(ax);
+        };
+        for (size_t head = 0; head < order.size(); ++head) {
+            const int q = (int)(order[head] / R), r = (int)(order[head] % R);
+            const int lo = soff[q], hi = soff[q + 1];
+            const int32_t* ke = key + hi;
+            const int f1 = (int)(std::upper_bound(key + lo, ke, -1) - key);
+            const int z1 = (int)(std::upper_bound(key + f1, ke, 0) - key);
+            // candidate topology arcs: phone 0, and the phones on r's arcs; visited in topology arc order
+            cand.clear(); seen.clear();
+            for (int x = f1; x < z1; ++x) cand.push_back(perm[x]);
+            for (int e = boff[r]; e < boff[r + 1]; ++e) {
+                const int l = ba[4 * e + 2];
+                if (l < 0 || std::find(seen.begin(), seen.end(), l) != seen.end()) continue;
+                seen.push_back(l);
+                const int p0 = (int)(std::lower_bound(key + z1, ke, l) - key), p1 = (int)(std::upper_bound(key + p0, ke, l) - key);
+                for (int y = p0; y < p1; ++y) cand.push_back(perm[y]);
+            }
+            std::sort(cand.begin(), cand.end());
+            for (int a : cand) {
+                const int32_t* t = topo_arcs + 4 * (size_t)a;
+                const int ph = topo_aux[a];
+                if (ph == 0) { emit((int)head, t[1], r, t[2], t[3], 0); continue; }
+                for (int e = boff[r]; e < boff[r + 1]; ++e)
+                    if (ba[4 * e + 2] == ph) emit((int)head, t[1], ba[4 * e + 1], t[2], fadd(t[3], ba[4 * e + 3]), bx ? bx[e] : ph);
+            }
+            for (int j = lo; j < f1; ++j)   // final arcs: both sides must be final here
+                for (int e = boff[r]; e < boff[r + 1]; ++e)
+                    if (ba[4 * e + 2] < 0) {
+                        arcs.push_back((int32_t)head); arcs.push_back(-1); arcs.push_back(-1);
+                        arcs.push_back(fadd(topo_arcs[4 * (size_t)perm[j] + 3], ba[4 * e + 3]));
+                        aux.push_back(-1);
+                    }
+        }
+        const int sf = (int)order.size();
+        const int64_t n = (int64_t)aux.size();
+        if (w + n > INT32_MAX) return wf_fail(WF_EUNSUPPORTED, "wf_compose_fsa_batch: more than 2^31 arcs");
+        if (fits && w + n <= cap) {
+            for (int64_t a = 0; a < n; ++a) {
+                int32_t* o = out_arcs + 4 * (size_t)(w + a);
+                o[0] = arcs[4 * a]; o[1] = arcs[4 * a + 1] < 0 ? sf : arcs[4 * a + 1]; o[2] = arcs[4 * a + 2]; o[3] = arcs[4 * a + 3];
+                out_aux[w + a] = aux[a];
+            }
+        } else {
+            fits = false;
+        }
+        w += n;
+        out_arc_off[b + 1] = (int32_t)w;
+        out_num_states[b] = sf + 1;
+    }
+    if (!fits) return wf_fail(WF_ENOSPC, "wf_compose_fsa_batch: arc capacity %lld < %lld", (long long)cap, (long long)w);
+    return WF_OK;
+}

@@ -82,13 +82,76 @@ class Lang:
         """datapipe.py:258-271."""
         return [[p for w in wids for p in self.lexicon[w]] for wids in wids_list]
 
-    def compile_training_graph(self, word_ids_list, device=None):
-        """Numerator graphs of a batch of word-id sequences (models.py:294-295): words -> phones through the
-        align lexicon, then topo o linear(phones) for the whole batch in one native call."""
+    def compile_training_graph(self, word_ids_list, device=None, optional_silence=None, sil_prob=None):
+        """Numerator graphs of a batch of word-id sequences (models.py:294-295).
+
+        Default: words -> phones through the align lexicon (last pronunciation of a word, as self.lexicon keeps it),
+        then topo o linear(phones) for the whole batch in one native call.
+        optional_silence=<phone symbol or id>: the phone-level graph of each utterance is built as Kaldi's L.fst would
+        give it through L_inv (datapipe.py:244-254) -- every pronunciation of every word (all lines of
+        align_lexicon.int) in parallel, an optional silence phone before the first word and after every word -- and
+        composed with the topology (wf_compose_fsa_batch).  sil_prob: None = unweighted arcs; else log(sil_prob) on a
+        silence arc and log(1 - sil_prob) where it is skipped (make_lexicon_fst.pl).  The arc weights and state
+        numbering of k2's route (intersect / invert / remove_epsilon) are not pinned here: k2 is not available."""
         if self.topo is None:
             self.load_topo()
-        g = compile_ctc_k2_graphs(self.topo, self.get_pids_list_from_wids_list(word_ids_list))
+        if optional_silence is None:
+            g = compile_ctc_k2_graphs(self.topo, self.get_pids_list_from_wids_list(word_ids_list))
+        else:
+            from .compile import compose
+            g = compose(self.topo, self.word_graphs(word_ids_list, optional_silence, sil_prob))
         return g.to(device) if device is not None else g
+
+    def load_pronunciations(self):
+        """All lines of phones/align_lexicon.int: word id -> list of pronunciations."""
+        prons = {}
+        with open(os.path.join(self._lang_dir, "phones", "align_lexicon.int")) as f:
+            for line in f:
+                lc = line.strip().split()
+                if lc:
+                    p = [int(x) for x in lc[2:]]
+                    if p not in prons.setdefault(int(lc[0]), []):
+                        prons[int(lc[0])].append(p)
+        return prons
+
+    def word_graphs(self, word_ids_list, optional_silence, sil_prob=None):
+        """Epsilon-free phone-level graphs of word sequences (labels = phones, aux_labels = word ids on the first arc
+        of a pronunciation): states b_i (after word i) and s_i (after word i and a silence); see compile_training_graph."""
+        import math
+        from .fsa import create_fsa_vec
+        sil = self.phone2idx[optional_silence] if isinstance(optional_silence, str) else int(optional_silence)
+        w_sil = math.log(sil_prob) if sil_prob else 0.0
+        w_no = math.log(1.0 - sil_prob) if sil_prob else 0.0
+        prons = self.load_pronunciations()
+        out = []
+        for wids in word_ids_list:
+            n = len(wids)
+            arcs, aux = [], []
+            nxt = [2 * (n + 1)]                  # b_i = 2 i, s_i = 2 i + 1, then the states inside pronunciations
+
+            def new_state():
+                nxt[0] += 1
+                return nxt[0] - 1
+            for i in range(n + 1):
+                arcs.append((2 * i, 2 * i + 1, sil, w_sil)); aux.append(0)
+            for i, w in enumerate(wids):
+                for p in prons[w]:
+                    if not p:
+                        raise ValueError(f"word {w} has an empty pronunciation")
+                    end = 2 * (i + 1)
+                    first_dst = end if len(p) == 1 else new_state()
+                    arcs.append((2 * i, first_dst, p[0], w_no)); aux.append(w)
+                    arcs.append((2 * i + 1, first_dst, p[0], 0.0)); aux.append(w)
+                    cur = first_dst
+                    for j in range(1, len(p)):
+                        d = end if j == len(p) - 1 else new_state()
+                        arcs.append((cur, d, p[j], 0.0)); aux.append(0)
+                        cur = d
+            fin = nxt[0]
+            arcs.append((2 * n, fin, -1, w_no)); aux.append(-1)
+            arcs.append((2 * n + 1, fin, -1, 0.0)); aux.append(-1)
+            out.append(Fsa.from_arcs(arcs, fin + 1, aux))
+        return create_fsa_vec(out)
 
 
 def write_lang_dir(lang_dir, lexicon, phones, topo, oov="<UNK>"):
