@@ -60,6 +60,10 @@ extern "C" {
 #define WF_PRUNED 8u      /* wf_fb_logsum is called with 0 < output_beam < inf: pass it to
                              wf_fb_workspace_bytes, wf_fb_logsum and wf_fb_backward alike (the tropical
                              first pass and its thresholds need workspace)                          */
+#define WF_PREZERO 16u    /* wf_fb_logsum(flags | WF_KEEP_AB | WF_PREZERO, grad != NULL): the gradient is NOT computed; the
+                             grad box is zero-filled on a side stream beside the sweeps, so that the
+                             wf_fb_backward(flags | WF_PREZERO, same grad) that follows only scatters the posteriors
+                             (the autograd split of loss and gradient without paying for the fill twice over)   */
 
 typedef struct {
     int32_t num_fsas;                 /* G                                                     */

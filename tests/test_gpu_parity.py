@@ -710,3 +710,23 @@ def test_loss_stats_kernel_matches_the_elementwise_formula():
         ok = np.isfinite(t)
         np.testing.assert_allclose(out[0], -t[ok].astype(np.float64).sum(), rtol=1e-5)
         assert out[1] == 1234 and out[2] == (~ok).sum()
+
+
+def test_autograd_split_prezero_and_second_backward():
+    # forward zero-fills the gradient buffer beside the sweeps (WF_PREZERO), backward only scatters; a second backward
+    # through the retained graph takes a fresh buffer; a view with padded strides takes the strided fill
+    c = util.random_case(71, "ctc", B=3, T=40, L=6, P=30)
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "sum")
+    V = c["V"]
+    big = torch.zeros(3, 40, V + 5)
+    big[:, :, :V] = torch.from_numpy(c["lp"])
+    for x in (torch.from_numpy(c["lp"]).to(DEV).requires_grad_(True), big.to(DEV)[:, :, :V].requires_grad_(True)):
+        dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
+        loss = wf.graphloss(c["fsa"], dense, reduction="sum")
+        loss.backward(retain_graph=True)
+        g1 = x.grad.clone()
+        x.grad = None
+        (2.0 * loss).backward()
+        np.testing.assert_allclose(loss.item(), want, rtol=TOT_RTOL)
+        np.testing.assert_allclose(g1.cpu().numpy(), wgrad, atol=GRAD_ATOL)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), 2 * wgrad, atol=2 * GRAD_ATOL)

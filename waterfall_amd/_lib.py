@@ -13,6 +13,7 @@ WF_DOUBLE_ACC = 1
 WF_TROPICAL = 2
 WF_KEEP_AB = 4
 WF_PRUNED = 8
+WF_PREZERO = 16
 
 
 class WfError(RuntimeError):

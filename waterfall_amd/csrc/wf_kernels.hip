@@ -3673,7 +3673,10 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     }
     g_tm.have_fwd = g_tm.on;
     g_tm.have_check = g_tm.on && P.lin;
-    if (grad) {
+    if (grad && (flags & WF_PREZERO)) {
+        // loss now, gradient later (wf_fb_backward with WF_PREZERO): the fill is done, ordered before whatever follows
+        if (overlap) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
+    } else if (grad) {
         if (overlap) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
         if ((rc = tm_record(3, st))) return rc;
         rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st);
@@ -3754,7 +3757,9 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     hipStream_t st = (hipStream_t)stream;
     if ((rc = tm_record(3, st))) return rc;
     // P.lin repeats the decision the forward call made; the fallback flags are still in the workspace
-    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, false, st);
+    // WF_PREZERO: the forward call zero-filled the box under exactly the condition below (its `overlap`)
+    const bool prezeroed = (flags & WF_PREZERO) && P.any_compact && !getenv("WF_NO_OVERLAP");
+    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, prezeroed, st);
     if (rc) return rc;
     if ((rc = tm_record(4, st))) return rc;
     g_tm.have_post = g_tm.on;

@@ -65,12 +65,18 @@ class _FbFunction(torch.autograd.Function):
                                               1 if need_grad else 0, C.byref(n)))
         ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
         tot = torch.empty(B, dtype=torch.float32, device=dev)
+        grad = None
+        if need_grad:
+            # the gradient buffer is zero-filled beside the sweeps of this call (WF_PREZERO); backward only scatters
+            grad = torch.empty_strided(lp.shape, lp.stride(), dtype=torch.float32, device=dev)
+            flags |= _lib.WF_PREZERO
         with torch.cuda.device(dev):
             _lib.check(lib.wf_fb_logsum(_np_ptr(gh), _ptr(gd), _np_ptr(graph.utt2fsa), _ptr(lp), lp.stride(0),
                                         lp.stride(1), N, T, V, _np_ptr(seg), B, beam, flags, None, _ptr(tot),
-                                        None, _ptr(ws), n.value, _stream(dev)))
+                                        _ptr(grad) if grad is not None else None, _ptr(ws), n.value, _stream(dev)))
         if need_grad:
             ctx.graph, ctx.dense, ctx.flags, ctx.ws, ctx.ws_bytes = graph, dense, flags, ws, n.value
+            ctx.grad = grad
             ctx.save_for_backward(lp, tot)
         return tot
 
@@ -84,11 +90,15 @@ class _FbFunction(torch.autograd.Function):
         seg = dense.supervision_segments.numpy()
         B = seg.shape[0]
         gs = gtot.to(torch.float32).contiguous()
-        grad = torch.empty_strided(lp.shape, lp.stride(), dtype=torch.float32, device=dev)
+        flags = ctx.flags
+        grad, ctx.grad = ctx.grad, None
+        if grad is None:   # a second backward through the same graph (retain_graph): fresh buffer, zero-filled by the call
+            grad = torch.empty_strided(lp.shape, lp.stride(), dtype=torch.float32, device=dev)
+            flags &= ~_lib.WF_PREZERO
         with torch.cuda.device(dev):
             _lib.check(lib.wf_fb_backward(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)),
                                           _np_ptr(graph.utt2fsa), _ptr(lp), lp.stride(0), lp.stride(1), N, T, V,
-                                          _np_ptr(seg), B, ctx.flags, _ptr(gs), _ptr(tot), _ptr(grad),
+                                          _np_ptr(seg), B, flags, _ptr(gs), _ptr(tot), _ptr(grad),
                                           _ptr(ctx.ws), ctx.ws_bytes, _stream(dev)))
         return grad, None, None, None, None
 
