@@ -1786,36 +1786,62 @@ __device__ __forceinline__ void log2_split(double v, double& e, float& f) {
     f = __builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(v));
 }
 
+// kCheckFR consecutive rows per wavefront, their loads in flight together (one row per wave is a chain of dependent
+// round trips -- utterance table, shifts, rows -- on 16 000 waves)
+constexpr int kCheckFR = 4;
+
 __global__ void __launch_bounds__(64) check_kernel(CheckArgs p) {
     const int lane = threadIdx.x;
-    const int t = blockIdx.x, u = blockIdx.y;
+    const int t0 = blockIdx.x * kCheckFR, u = blockIdx.y;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int T = (int)U[WF_U_T];
-    if (t > T) return;
-    if (p.force) { if (t == 0 && lane == 0) p.flag[u] = 1; return; }
+    if (t0 > T) return;
+    if (p.force) { if (t0 == 0 && lane == 0) p.flag[u] = 1; return; }
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
     const int S = (int)U[WF_U_S];
     const double tot2 = p.tot2[u];
     if (tot2 == (double)-INFINITY) {
         // zero total: fine when no path of this length exists, otherwise the sweep underflowed
-        if (t == 0 && lane == 0 && T >= I[WF_I_MINLEN]) p.flag[u] = 1;
+        if (t0 == 0 && lane == 0 && T >= I[WF_I_MINLEN]) p.flag[u] = 1;
         return;
     }
-    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
-    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)t * S;
-    // alpha row t came from forward step t-1, beta row t from backward step T-1-t
-    const double cst = p.ctot2[u] - tot2 - p.aoff[U[WF_U_OFFS] + lin_shift_index(t - 1, p.grp, p.lag)] -
-                       p.boff[U[WF_U_OFFS] + lin_shift_index(T - 1 - t, p.grp, p.lag)];
-    float sum = 0.f;
-    for (int s = lane; s < S - 1; s += 64) {   // the super-final state carries no mass at t <= T
-        double ea, eb;
-        float fa, fb;
-        log2_split(arow[s], ea, fa);
-        log2_split(brow[s], eb, fb);
-        sum += __builtin_amdgcn_exp2f((float)(ea + eb + cst) + (fa + fb));   // exp2(-inf) = 0 for dead states
+    const double* abase = p.alpha + U[WF_U_ALPHA];
+    const double* bbase = p.beta + U[WF_U_BETA];
+    const double c0 = p.ctot2[u] - tot2;
+    double cst[kCheckFR];
+    float sum[kCheckFR];
+#pragma unroll
+    for (int r = 0; r < kCheckFR; ++r) {
+        const int t = min(t0 + r, T);   // rows past T repeat row T (not judged)
+        // alpha row t came from forward step t-1, beta row t from backward step T-1-t
+        cst[r] = c0 - p.aoff[U[WF_U_OFFS] + lin_shift_index(t - 1, p.grp, p.lag)] -
+                 p.boff[U[WF_U_OFFS] + lin_shift_index(T - 1 - t, p.grp, p.lag)];
+        sum[r] = 0.f;
     }
-    sum = wave_sum(sum);
-    if (lane == 0 && !(fabsf(sum - 1.f) <= kCheckTol)) p.flag[u] = 1;
+    for (int s = lane; s < S - 1; s += 64) {   // the super-final state carries no mass at t <= T
+        double a[kCheckFR], b[kCheckFR];
+#pragma unroll
+        for (int r = 0; r < kCheckFR; ++r) {
+            const int64_t row = (int64_t)min(t0 + r, T) * S;
+            a[r] = abase[row + s];
+            b[r] = bbase[row + s];
+        }
+#pragma unroll
+        for (int r = 0; r < kCheckFR; ++r) {
+            double ea, eb;
+            float fa, fb;
+            log2_split(a[r], ea, fa);
+            log2_split(b[r], eb, fb);
+            sum[r] += __builtin_amdgcn_exp2f((float)(ea + eb + cst[r]) + (fa + fb));   // exp2(-inf) = 0 for dead states
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < kCheckFR; ++r) {
+        const float v = wave_sum(sum[r]);
+        if (t0 + r <= T && !(fabsf(v - 1.f) <= kCheckTol)) bad = true;
+    }
+    if (lane == 0 && bad) p.flag[u] = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3629,7 +3655,7 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
         CheckArgs k{a.blob, a.utt, (const double*)a.alpha, (const double*)a.beta, a.aoff, a.boff, a.tot2, a.ctot2,
                     (int32_t*)(ws + P.off_flag), lgrp, llag,
                     env_int("WF_FORCE_FALLBACK", 0)};
-        hipLaunchKernelGGL(check_kernel, dim3(P.Tlong + 1, B), dim3(64), 0, st, k);
+        hipLaunchKernelGGL(check_kernel, dim3((P.Tlong + 1 + kCheckFR - 1) / kCheckFR, B), dim3(64), 0, st, k);
         HIP_TRY(hipGetLastError());
         SweepCfg fc = sweep_config_minimal(P, ab);
         SweepArgs fa = a;
