@@ -279,7 +279,8 @@ def test_full_size_mmictc_denominator_properties(oracle_lib):
 
 SWEEP_PATHS = {
     "default": {},
-    "lin_lds": {"WF_NO_BAND_SWEEP": "1"},
+    "lin_lds": {"WF_NO_BAND_SWEEP": "1"},                                 # <= 64 states: the wave-resident variant (ds_bpermute)
+    "lin_lds_no_wave": {"WF_NO_BAND_SWEEP": "1", "WF_NO_WAVE_SWEEP": "1"},  # state vector through the LDS whatever the size
     "log_generic": {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "1"},
     "band_then_fallback": {"WF_FORCE_FALLBACK": "1"},
     "lin_then_fallback": {"WF_NO_BAND_SWEEP": "1", "WF_FORCE_FALLBACK": "1"},

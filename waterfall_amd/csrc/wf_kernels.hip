@@ -961,7 +961,17 @@ __device__ __forceinline__ int64_t uni(int64_t v) {
     return ((int64_t)hi << 32) | lo;
 }
 
-template <int HD, int NTMAX>
+// lane `srclane`'s copy of v (all lanes execute it; ds_bpermute addresses lanes in bytes)
+__device__ __forceinline__ double bperm_d(double v, int srclane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(srclane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(srclane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// WV (graphs of at most 64 states, one wavefront: the small denominators, e.g. cfg2's 60-state 2state topology): the
+// state vector never leaves the registers -- a lane fetches its source states' values with ds_bpermute instead of an
+// LDS write -> barrier -> read round trip, and the exponent bookkeeping stays in the wave.
+template <int HD, int NTMAX, bool WV = false>
 __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int D = WF_REG_DEG;
@@ -1041,19 +1051,25 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
     double* goff = (dir ? p.boff : p.aoff) + uni(U[WF_U_OFFS]);
 
     // ---- initial vector (alpha_0 = delta(start); beta_T = final weights) and its exponent maximum
+    double av = 0.0;   // WV: this lane's state value
+    int wv_emax = 0;   // WV: exponent maximum of the row that ended the previous group
     {
         const float* fb = (const float*)(blob + uni(I[WF_I_FINB_LOG]));
         int emax = 0;
         for (int s = tid; s < S; s += nt) {
             const double v = dir ? exp((double)fb[s]) : (s == 0 ? 1.0 : 0.0);
-            cur[s] = v;
+            if (WV) av = v; else cur[s] = v;
             arena[(int64_t)(dir ? T : 0) * S + s] = v;
             emax = max(emax, f64_exp_field(v));
         }
         emax = wave_max_i(emax);
-        if (tid < 16) rexp[tid] = 0;
-        __syncthreads();
-        if (lane == 0) rexp[wave] = emax;
+        if (WV) {
+            wv_emax = emax;
+        } else {
+            if (tid < 16) rexp[tid] = 0;
+            __syncthreads();
+            if (lane == 0) rexp[wave] = emax;
+        }
         if (tid == 0) goff[0] = 0.0;
     }
     double* srow = arena + (int64_t)(dir ? (T - 1) : 1) * S;   // row written by step 0, then +-S per step
@@ -1081,17 +1097,17 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
 #pragma unroll
     for (int j = 0; j < HDN; ++j) hqc[j] *= hW[j];
     double cum = 0.0, cum_last = 0.0;   // cumulative power-of-two shift (log2 units) carried by the rows
-    __syncthreads();
+    if (!WV) __syncthreads();
 
     auto do_step = [&](const int step, const int k) __attribute__((always_inline)) {
         // ---- critical path, part 1: issue the LDS reads of the source states' alpha
         double a[D], ha[HDN];
 #pragma unroll
-        for (int i = 0; i < D; ++i) a[i] = cur[src[i]];
+        for (int i = 0; i < D; ++i) a[i] = WV ? bperm_d(av, src[i]) : cur[src[i]];
 #pragma unroll
-        for (int j = 0; j < HDN; ++j) ha[j] = (HD > 0) ? cur[hsrc[j]] : 0.0;
+        for (int j = 0; j < HDN; ++j) ha[j] = (HD > 0) ? (WV ? bperm_d(av, hsrc[j]) : cur[hsrc[j]]) : 0.0;
         int4 rx[4];
-        if (k == 0) {
+        if (k == 0 && !WV) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) rx[i] = ((const int4*)rexp)[i];
         }
@@ -1108,10 +1124,15 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
         cum_last = cum;
         if (k == 0 && !(p.ablate & 4)) {
             // rescale decision from the row finished at the end of the previous group
-            int4 m4 = rx[0];
+            int emax;
+            if (WV) {
+                emax = wv_emax;
+            } else {
+                int4 m4 = rx[0];
 #pragma unroll
-            for (int i = 1; i < 4; ++i) { m4.x = max(m4.x, rx[i].x); m4.y = max(m4.y, rx[i].y); m4.z = max(m4.z, rx[i].z); m4.w = max(m4.w, rx[i].w); }
-            const int emax = max(max(m4.x, m4.y), max(m4.z, m4.w));
+                for (int i = 1; i < 4; ++i) { m4.x = max(m4.x, rx[i].x); m4.y = max(m4.y, rx[i].y); m4.z = max(m4.z, rx[i].z); m4.w = max(m4.w, rx[i].w); }
+                emax = max(max(m4.x, m4.y), max(m4.z, m4.w));
+            }
             const int sh = emax > 0 ? (1023 + kLinBias) - emax : 0;
 #pragma unroll
             for (int i = 0; i < D; ++i) qn[i] = ldexp(qn[i], sh);
@@ -1127,7 +1148,7 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
 #pragma unroll
             for (int j = 0; j < HDN; ++j) part = fma(ha[j], hqc[j], part);
             double tot_h = wave_sum_d(part);
-            if (nw > 1) {
+            if (!WV && nw > 1) {
                 if (lane == 0) red[wave] = tot_h;
                 __syncthreads();
                 if (tid == 0) {
@@ -1135,7 +1156,9 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
                     for (int i = 1; i < nw; ++i) tot_h += red[i];
                 }
             }
-            if (tid == 0) {
+            if (WV) {
+                if (tid == over) { av = tot_h; srow[over] = tot_h; emine = f64_exp_field(tot_h); }
+            } else if (tid == 0) {
                 nxt[over] = tot_h;
                 srow[over] = tot_h;
                 emine = f64_exp_field(tot_h);
@@ -1145,21 +1168,24 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
 #pragma unroll
         for (int i = 1; i < D; ++i) v = fma(a[i], qc[i], v);
         if (mine) {
-            nxt[tid] = v;
+            if (WV) av = v; else nxt[tid] = v;
             if (!(p.ablate & 1)) srow[tid] = v;
             emine = max(emine, f64_exp_field(v));
         }
         if (k == kLD - 1 && !(p.ablate & 4)) {
             const int em = wave_max_i(emine);
-            if (lane == 0) rexp[wave] = em;
+            if (WV) wv_emax = em;
+            else if (lane == 0) rexp[wave] = em;
         }
         srow += sstep;
 #pragma unroll
         for (int i = 0; i < D; ++i) qc[i] = qn[i];
 #pragma unroll
         for (int j = 0; j < HDN; ++j) hqc[j] = hqn[j];
-        __syncthreads();
-        double* t_ = cur; cur = nxt; nxt = t_;
+        if (!WV) {
+            __syncthreads();
+            double* t_ = cur; cur = nxt; nxt = t_;
+        }
     };
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
     int t0 = 0;
@@ -1180,7 +1206,15 @@ __global__ void __launch_bounds__(NTMAX) sweep_lin_kernel(SweepArgs p) {
         const int32_t* fsrc = blob + I[WF_I_FIN_SRC];
         const float* fw = (const float*)(blob + I[WF_I_FIN_W]);
         double part = 0.0, csum = 0.0;
-        for (int i = tid; i < NF; i += nt) part = fma(cur[fsrc[i]], exp((double)fw[i]), part);
+        if (WV) {   // every lane takes part in the exchange; uniform trip count
+            for (int i0 = 0; i0 < NF; i0 += 64) {
+                const int i = i0 + lane;
+                const double a = bperm_d(av, i < NF ? fsrc[i] : 0);
+                if (i < NF) part = fma(a, exp((double)fw[i]), part);
+            }
+        } else {
+            for (int i = tid; i < NF; i += nt) part = fma(cur[fsrc[i]], exp((double)fw[i]), part);
+        }
         const double* crow = p.cmax + U[WF_U_ROW0];
         for (int t = tid; t < T; t += nt) csum += crow[t];
         part = wave_sum_d(part);
@@ -3365,7 +3399,8 @@ int launch_sweep_lin(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
     // two register budgets: workgroups of <= 256 lanes may use up to 512 VGPRs per lane
 #define WF_LAUNCH_LIN(HH)                                                                             \
     do {                                                                                              \
-        if (c.threads <= 256) hipLaunchKernelGGL((sweep_lin_kernel<HH, 256>), grid, block, c.lds, st, a); \
+        if (c.threads == 64 && !env_int("WF_NO_WAVE_SWEEP", 0)) hipLaunchKernelGGL((sweep_lin_kernel<HH, 256, true>), grid, block, c.lds, st, a); \
+        else if (c.threads <= 256) hipLaunchKernelGGL((sweep_lin_kernel<HH, 256>), grid, block, c.lds, st, a); \
         else hipLaunchKernelGGL((sweep_lin_kernel<HH, kMaxThreads>), grid, block, c.lds, st, a);        \
     } while (0)
     if (c.HD == 0) WF_LAUNCH_LIN(0);
