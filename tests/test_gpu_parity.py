@@ -279,6 +279,7 @@ def test_full_size_mmictc_denominator_properties(oracle_lib):
 
 SWEEP_PATHS = {
     "default": {},
+    "no_gen_wave": {"WF_NO_GEN_SWEEP": "1"},                              # cyclic graphs <= 64 states: sweep_lin instead of the wave kernel's general mode
     "lin_lds": {"WF_NO_BAND_SWEEP": "1"},                                 # <= 64 states: the wave-resident variant (ds_bpermute)
     "lin_lds_no_wave": {"WF_NO_BAND_SWEEP": "1", "WF_NO_WAVE_SWEEP": "1"},  # state vector through the LDS whatever the size
     "log_generic": {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "1"},

@@ -1519,11 +1519,17 @@ constexpr size_t kBandLds = kBandLdsUsed > 84 * 1024 ? kBandLdsUsed : 84 * 1024;
 
 // MM: arcs per (position, distance) cell (1: deterministic topologies); WE: every arc weight is 0 and
 // MM == 1, so a cell's probability is the staged emission itself (no multiply)
-template <int R, int BW, int MM, bool WE>
+// GEN (R = BW = MM = 1): ANY graph of at most 64 non-final states whose states have <= WF_REG_DEG arcs, but for one
+// state of up to 64 (the small denominators: cfg2's 2state topology, S = 60, hub fan-in 59).  lane = state; a lane
+// fetches its sources' values with ds_bpermute instead of the DPP shift, the hub's arcs sit one per lane and are
+// summed with the DPP tree.  Stager, chunking, rescaling and the total are the banded kernel's.
+template <int R, int BW, int MM, bool WE, bool GEN = false>
 __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
-    constexpr int NQ = R * (BW + 1), C = kBandC;
+    constexpr int GD = WF_REG_DEG;
+    constexpr int NQ = GEN ? GD + 1 : R * (BW + 1), C = kBandC;
     static_assert(MM >= 1 && MM <= WF_BAND_MAX_M && (!WE || MM == 1), "cell capacity");
     static_assert(BW <= R, "sources must sit in the same lane or the previous one");
+    static_assert(!GEN || (R == 1 && BW == 1 && MM == 1), "general-graph mode: one state per lane");
     extern __shared__ __align__(16) unsigned char smem[];
     const unsigned long long tstart = __builtin_amdgcn_s_memtime();
     // LDS: staged emission rows [2][C][kBandKP] x 8 B | 2 x 64 exponent words | 2 shift words
@@ -1564,7 +1570,7 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         for (int r = 0; r < R; ++r) {
             const int pp = lane * R + r;
             int st = -1;
-            if (pp < Sn) st = order[dir ? Sn - 1 - pp : pp];
+            if (pp < Sn) st = GEN ? pp : order[dir ? Sn - 1 - pp : pp];
             a[r] = st < 0 ? 0.0 : (dir ? exp((double)fb[st]) : (st == 0 ? 1.0 : 0.0));
             sidx[r] = st < 0 ? S - 1 : st;
             arena[(int64_t)(dir ? T : 0) * S + sidx[r]] = a[r];   // alpha_0 / beta_T
@@ -1573,8 +1579,29 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         // which the stager keeps at 0) and exp(weight)
         unsigned coff[NQ][MM];
         double cw[NQ][MM];
+        int gsrc[NQ];   // GEN: the lane (= state) an arc comes from; slot GD is this lane's arc of the hub state
+        int over = -1;
+        if (GEN) {
+            const int32_t* g_off = blob + uni(I[dir ? WF_I_OUT_OFF : WF_I_IN_OFF]);
+            const int32_t* g_oth = blob + uni(I[dir ? WF_I_OUT_DST : WF_I_IN_SRC]);
+            const int32_t* g_col = blob + uni(I[dir ? WF_I_OUT_COL : WF_I_IN_COL]);
+            const float* g_w = (const float*)(blob + uni(I[dir ? WF_I_OUT_W : WF_I_IN_W]));
+            if (uni(I[dir ? WF_I_NOVER_OUT : WF_I_NOVER_IN]) > 0) over = uni(I[dir ? WF_I_OVER_OUT : WF_I_OVER_IN]);
+            int a0 = 0, deg = 0;
+            if (lane < Sn && lane != over) { a0 = g_off[lane]; deg = g_off[lane + 1] - a0; }
+            int h0 = 0, h1 = 0;
+            if (over >= 0) { h0 = g_off[over]; h1 = g_off[over + 1]; }
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) {
+            for (int j = 0; j < NQ; ++j) {
+                const int arc = j < GD ? a0 + j : h0 + lane;
+                const bool on = j < GD ? j < deg : h0 + lane < h1;
+                gsrc[j] = on ? g_oth[arc] : 0;
+                coff[j][0] = (unsigned)(on ? g_col[arc] : K) * 8u;
+                cw[j][0] = on ? exp((double)g_w[arc]) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NQ && !GEN; ++j) {
             const int r = j / (BW + 1), d = j % (BW + 1);
             const int pp = lane * R + r;
             const bool cell = pp < Sn && d <= gbw;
@@ -1613,6 +1640,17 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
             }
         };
         auto step = [&](const double (&q)[NQ]) __attribute__((always_inline)) {
+            if (GEN) {
+                double v = bperm_d(a[0], gsrc[0]) * q[0];
+#pragma unroll
+                for (int j = 1; j < GD; ++j) v = fma(bperm_d(a[0], gsrc[j]), q[j], v);
+                const double hub = wave_sum_d(bperm_d(a[0], gsrc[GD]) * q[GD]);   // 0 without a hub state
+                if (lane == over) v = hub;
+                a[0] = v;
+                srow[sidx[0]] = v;
+                srow += sstep;
+                return;
+            }
             double nb[BW];   // nb[j]: the state at position lane*R - 1 - j (slot R-1-j of lane - 1)
 #pragma unroll
             for (int j = 0; j < BW; ++j) nb[j] = wave_shr1_d(a[R - 1 - j]);
@@ -1683,7 +1721,7 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int pp = lane * R + r;
-                if (pp < Sn) part = fma(a[r], exp((double)fb[order[pp]]), part);
+                if (pp < Sn) part = fma(a[r], exp((double)fb[GEN ? pp : order[pp]]), part);
             }
             double csum = 0.0;
             const double* crow = p.cmax + uni(U[WF_U_ROW0]);
@@ -2988,7 +3026,7 @@ RegCfg lin_config(const Plan& P);
 size_t sweep_lds_bytes(const Plan& P, size_t acc_bytes);
 int env_int(const char* name, int dflt);
 constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where nothing else fits, until measured otherwise
-struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; };
+struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; bool gen = false; };
 BandSel band_config(const Plan& P);
 bool linbig_config(const Plan& P);
 
@@ -3355,20 +3393,31 @@ int launch_sweep_linbig(const Plan& P, SweepArgs a, int B, hipStream_t st) {
 BandSel band_config(const Plan& P) {
     BandSel b;
     const int no_band = env_int("WF_NO_BAND_SWEEP", 0);   // test hook, read per call
-    if (no_band || P.band_bw < 0 || P.band_sn < 1 || P.kmax >= kBandKP) return b;
+    if (no_band || P.band_sn < 1 || P.kmax >= kBandKP) return b;
+    b.grp = kBandC;
+    if (P.band_bw < 0) {
+        // no banded order (a cycle besides self-loops: denominators): the general-graph mode of the wave kernel, for
+        // graphs of at most 64 non-final states with <= WF_REG_DEG arcs per state but for one state of up to 64
+        if (env_int("WF_NO_GEN_SWEEP", 0) || P.band_sn > 64 || !P.reg_ok_in || !P.reg_ok_out || P.over_deg_in > 64 || P.over_deg_out > 64)
+            return b;
+        b.gen = true;
+        b.R = b.BW = b.M = 1;
+        b.we = P.band_we;
+        b.ok = true;
+        return b;
+    }
     b.BW = P.band_bw <= 2 ? 2 : 4;
     b.R = std::max(b.BW, (P.band_sn + 63) / 64);
     if (b.R > WF_BAND_MAX_R) return b;
-    b.grp = kBandC;
     b.M = P.band_m <= 1 ? 1 : 2;
     b.we = b.M == 1 && P.band_we;
     b.ok = true;
     return b;
 }
 
-template <int R, int BW, int MM, bool WE>
+template <int R, int BW, int MM, bool WE, bool GEN = false>
 int launch_band_one(const SweepArgs& a, int B, hipStream_t st) {
-    auto k = sweep_band_kernel<R, BW, MM, WE>;
+    auto k = sweep_band_kernel<R, BW, MM, WE, GEN>;
     if (kBandLds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds));
     hipLaunchKernelGGL(k, dim3(B * 2), dim3(128), kBandLds, st, a);
@@ -3379,6 +3428,7 @@ int launch_band_one(const SweepArgs& a, int B, hipStream_t st) {
 int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st) {
     static const int prof = env_int("WF_SWEEP_PROFILE", 0);
     a.ablate = prof;
+    if (b.gen) return b.we ? launch_band_one<1, 1, 1, true, true>(a, B, st) : launch_band_one<1, 1, 1, false, true>(a, B, st);
 #define WF_BAND_CASE(RR, WW)                                                                     \
     if (b.BW == WW && b.R == RR)                                                                  \
         return b.we ? launch_band_one<RR, WW, 1, true>(a, B, st)                                   \
