@@ -3614,6 +3614,8 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
         if (need <= 2) hipLaunchKernelGGL(post_small_kernel<2>, grid, dim3(64), lds2, st, q);
         else if (need <= 3) hipLaunchKernelGGL(post_small_kernel<3>, grid, dim3(64), lds2, st, q);   // cfg3: S ~ 130, A ~ 323 (the kernel is instruction-bound)
         else if (need <= 4) hipLaunchKernelGGL(post_small_kernel<4>, grid, dim3(64), lds2, st, q);
+        else if (need <= 5) hipLaunchKernelGGL(post_small_kernel<5>, grid, dim3(64), lds2, st, q);   // cfg2 numerators: A ~ 562
+        else if (need <= 6) hipLaunchKernelGGL(post_small_kernel<6>, grid, dim3(64), lds2, st, q);
         else hipLaunchKernelGGL(post_small_kernel<8>, grid, dim3(64), lds2, st, q);
         HIP_TRY(hipGetLastError());
         return WF_OK;
