@@ -2811,16 +2811,27 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     const int lane = threadIdx.x;
     const int f0 = blockIdx.x * kPostFR, q = blockIdx.y;
     const int u = p.seq2utt[q];
-    if (u < 0) return;
-    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int64_t* U = p.utt + (int64_t)max(u, 0) * WF_U_WORDS;
     const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
-    const double tot = p.totd[u];
-    const int t0 = max(f0 - start, 0), t1 = min(f0 + kPostFR - start, T);
-    if (t0 >= t1 || tot == (double)-INFINITY) return;
-    const int S = (int)U[WF_U_S], A = (int)U[WF_U_A], K = (int)U[WF_U_K];
+    const double tot = u >= 0 ? p.totd[u] : (double)-INFINITY;
+    const int t0 = max(f0 - start, 0), t1 = (u >= 0 && tot != (double)-INFINITY) ? min(f0 + kPostFR - start, T) : 0;
+    const int K = (int)U[WF_U_K], direct = (int)U[WF_U_DIRECT];
+    if (!p.skip_zero) {
+        // rows not pre-zeroed (graphs whose columns are the labels themselves: no side-stream fill): this wave zeroes what
+        // it does not write -- whole rows outside the segment / of infeasible utterances, columns K.. of the others
+        for (int f = f0; f < min(f0 + kPostFR, p.Tmax); ++f) {
+            const int t = f - start;
+            const bool live = t >= t0 && t < t1;
+            float* row = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
+            for (int c = (live ? K : 0) + lane; c < p.V; c += 64) row[c] = 0.f;
+        }
+    }
+    if (t0 >= t1) return;
+    const int S = (int)U[WF_U_S], A = (int)U[WF_U_A];
     const double* abase = p.alpha + U[WF_U_ALPHA];
     const double* bbase = p.beta + U[WF_U_BETA];
-    const float* ebase = p.E + U[WF_U_E];
+    const float* ebase = direct ? p.lp + (int64_t)q * p.strideB + (int64_t)start * p.strideT : p.E + U[WF_U_E];
+    const int64_t epitch = direct ? p.strideT : K;
     const bool lin = !p.flag[u];   // flagged: the fallback left natural-log fp64 rows
     const int32_t* loff = p.blob + U[WF_U_LAB_OFF];
     const int32_t* lsrc = p.blob + U[WF_U_LAB_SRC];
@@ -2848,7 +2859,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
 #pragma unroll
     for (int i = 0; i < PSS; ++i) {
         const int k = min(lane + i * 64, K - 1);
-        k0[i] = loff[k]; k1[i] = kend[i] = loff[k + 1]; klab[i] = labels[k];
+        k0[i] = loff[k]; k1[i] = kend[i] = loff[k + 1]; klab[i] = direct ? k : labels[k];
         const bool mine = lane + i * 64 < K;
         heavy[i] = __ballot(mine && k1[i] - k0[i] > kPostHeavy);
         if (!mine || k1[i] - k0[i] > kPostHeavy) k1[i] = k0[i];   // nothing left for the per-lane loop
@@ -2860,7 +2871,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     auto fetch = [&](const int t) __attribute__((always_inline)) {
         const double* arow = abase + (int64_t)t * S;
         const double* brow = bbase + (int64_t)(t + 1) * S;
-        const float* erow = ebase + (int64_t)t * K;
+        const float* erow = ebase + (int64_t)t * epitch;
 #pragma unroll
         for (int i = 0; i < PSS; ++i) {
             const int s = min(lane + i * 64, S - 1);
@@ -3605,11 +3616,14 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     q.acap = (P.maxlabdeg > 8 && P.amax <= 8192) ? (int)align_up(P.amax, 4) : 0;
     q.skip_zero = skip_zero ? 1 : 0;
     size_t lds = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
-    if (P.lin && skip_zero && !getenv("WF_NO_POST_SMALL") && P.all_compact && P.amax >= 1 && P.amax <= 128 * 8 && P.smax <= 64 * 8 &&
-        P.kmax_compact <= 64 * 8 && q.ecap > 0) {
+    // pre-zeroed rows (some graph compact: the side-stream fill covered the whole box), or only graphs whose columns are the
+    // labels (the kernel zeroes the few columns it does not write)
+    if (P.lin && (skip_zero || !P.any_compact) && !getenv("WF_NO_POST_SMALL") && P.amax >= 1 && P.amax <= 128 * 8 && P.smax <= 64 * 8 &&
+        P.kmax <= 64 * 8) {
+        q.ecap = (int)align_up(P.kmax, 4);
         q.acap = (int)align_up(P.amax, 4);
         size_t lds2 = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
-        const int need = std::max(std::max((P.smax + 63) / 64, (P.kmax_compact + 63) / 64), (P.amax + 127) / 128);
+        const int need = std::max(std::max((P.smax + 63) / 64, (P.kmax + 63) / 64), (P.amax + 127) / 128);
         const dim3 grid((Tmax + kPostFR - 1) / kPostFR, num_seqs);
         if (need <= 2) hipLaunchKernelGGL(post_small_kernel<2>, grid, dim3(64), lds2, st, q);
         else if (need <= 3) hipLaunchKernelGGL(post_small_kernel<3>, grid, dim3(64), lds2, st, q);   // cfg3: S ~ 130, A ~ 323 (the kernel is instruction-bound)
