@@ -30,6 +30,16 @@ for case in range(n):
         if k.startswith("WF_"):
             del os.environ[k]
     os.environ.update(env)
+    if rng.integers(2):   # start offsets, unused sequences, permuted sequence indices
+        N, pad = B + int(rng.integers(0, 3)), int(rng.integers(0, 6))
+        lp2 = np.log(np.full((N, T + pad, c["V"]), 1.0 / c["V"], dtype=np.float32))
+        perm = rng.permutation(N)[:B]
+        segs2 = c["segs"].copy()
+        for i in range(B):
+            st = int(rng.integers(0, T + pad - segs2[i, 2] + 1))
+            lp2[perm[i], st:st + segs2[i, 2]] = c["lp"][i, :segs2[i, 2]]
+            segs2[i, 0], segs2[i, 1] = perm[i], st
+        c["lp"], c["segs"] = lp2, segs2
     x = torch.from_numpy(c["lp"]).cuda().requires_grad_(True)
     dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
     loss = wf.graphloss(c["fsa"], dense, reduction="none")
@@ -41,7 +51,8 @@ for case in range(n):
         and np.all(np.isfinite(g))
     best = wf.best_path(c["fsa"], dense)
     for i, gr in enumerate(c["ographs"]):
-        s, path = o.viterbi(gr, c["lp"][i], int(c["segs"][i, 2]))
+        sq, st, tt = (int(v) for v in c["segs"][i])
+        s, path = o.viterbi(gr, c["lp"][sq, st:st + tt], tt)
         if best["scores"][i].item() != s and not (np.isinf(s) and np.isinf(best["scores"][i].item())):
             ok = False
     if not ok:
