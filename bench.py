@@ -256,6 +256,33 @@ def cpu_baseline(wl, budget_s=12.0):
     return out
 
 
+def viterbi_bench(dev, S, B=8, T=500, V=5001, reps=3):
+    """cfg5: tropical best path + back-trace on a synthetic TLG-like graph (A = 3 S) shared by
+    the batch; exact search.  Algorithmic bytes per utterance-frame: 4 V + 16 A + 4 S."""
+    from waterfall_amd.synth import synth_decoding_graph
+    g = synth_decoding_graph(777, S, V)
+    arcs = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
+    one = wf.Fsa(arcs, g["aux"], [0, arcs.shape[0]], [g["num_states"]])
+    fsa = wf.create_fsa_vec([one] * B)
+    gen = torch.Generator(device=dev).manual_seed(777)
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=gen, device=dev) * 3.0, -1)
+    dense = wf.DenseFsaVec(lp, torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32))
+    wf.best_path(fsa, dense)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        wf.best_path(fsa, dense)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / reps
+    A = arcs.shape[0]
+    return {"ms_per_call": ms, "us_per_frame": ms * 1e3 / T, "frames_per_s": B * T / (ms * 1e-3),
+            "algorithmic_GBps": B * T * (4 * V + 16 * A + 4 * S) / (ms * 1e-3) / 1e9,
+            "desc": f"cfg5 Viterbi + back-trace, synthetic TLG-like graph S={S} A={A}, B={B}, T={T}, V={V}, exact search, "
+                    "includes the host-side label extraction of wf.best_path"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +293,8 @@ def main():
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--others", action="store_true", help="also time the other BASELINE workloads (N=1)")
+    ap.add_argument("--others", action="store_true", help="(default at N=1) also time the other BASELINE workloads")
+    ap.add_argument("--no-others", action="store_true", help="headline only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -344,7 +372,7 @@ def main():
         out["path_GBps_survey_8d"] = kb["path_survey_8d"] / (ms_step * 1e-3) / 1e9
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl)
-        if args.others and world == 1:
+        if world == 1 and not args.no_others and (args.others or default_wl):
             others = {}
             for name in WORKLOADS:
                 if name == args.workload:
@@ -358,6 +386,9 @@ def main():
                                 "arc_updates_per_sec": 2 * w2.arc_updates / (d2 / n2), "kernels_ms": k2,
                                 "desc": WORKLOADS[name]["desc"]}
                 del w2
+                torch.cuda.empty_cache()
+            for S in (100_000, 1_000_000):
+                others["cfg5_viterbi_S%.0e" % S] = viterbi_bench(dev, S)
                 torch.cuda.empty_cache()
             out["other_workloads"] = others
         print(json.dumps(out))
