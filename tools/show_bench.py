@@ -16,6 +16,9 @@ for line in open(sys.argv[1]):
         c = d["cpu_baseline"]
         print(f"   cpu: {c['value']:.4g} frames/s on {c['cores']} cores ({c['kind']})")
     for k, v in d.get("other_workloads", {}).items():
+        if "error" in v:
+            print(f"   {k:28s} ERROR {v['error']}")
+            continue
         if "ms_per_call" in v:
             print(f"   {k:28s} {v['frames_per_s']:.4g} f/s  {v['ms_per_call']:.3f} ms/call  {v['us_per_frame']:.1f} us/frame  {v['algorithmic_GBps']:.0f} GB/s (algorithmic)")
             continue
