@@ -371,7 +371,10 @@ def main():
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
         out["path_GBps_survey_8d"] = kb["path_survey_8d"] / (ms_step * 1e-3) / 1e9
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(wl)
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl)
+            except Exception as e:   # noqa: BLE001  (the GPU numbers above stand on their own)
+                out["cpu_baseline"] = {"error": repr(e)}
         if world == 1 and not args.no_others and (args.others or default_wl):
             others = {}
             # (a failure here must not cost the headline line: it is recorded in place of the numbers)
