@@ -259,14 +259,9 @@ def cpu_baseline(wl, budget_s=12.0):
 def viterbi_bench(dev, S, B=8, T=500, V=5001, reps=3):
     """cfg5: tropical best path + back-trace on a synthetic TLG-like graph (A = 3 S) shared by
     the batch; exact search.  Algorithmic bytes per utterance-frame: 4 V + 16 A + 4 S."""
-    from waterfall_amd.synth import synth_decoding_graph
-    g = synth_decoding_graph(777, S, V)
-    arcs = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
-    one = wf.Fsa(arcs, g["aux"], [0, arcs.shape[0]], [g["num_states"]])
-    fsa = wf.create_fsa_vec([one] * B)
-    gen = torch.Generator(device=dev).manual_seed(777)
-    lp = torch.log_softmax(torch.randn(B, T, V, generator=gen, device=dev) * 3.0, -1)
-    dense = wf.DenseFsaVec(lp, torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32))
+    from waterfall_amd.synth import best_path_checksum, cfg5_workload
+    g, fsa, lp, dense = cfg5_workload(dev, S, B, T, V)
+    arcs = fsa.arcs
     wf.best_path(fsa, dense)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -277,7 +272,10 @@ def viterbi_bench(dev, S, B=8, T=500, V=5001, reps=3):
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / reps
     A = arcs.shape[0]
-    return {"ms_per_call": ms, "us_per_frame": ms * 1e3 / T, "frames_per_s": B * T / (ms * 1e-3),
+    out = wf.best_path(fsa, dense)
+    csum = best_path_checksum(out["scores"].cpu().numpy(), out["arcs"].cpu().numpy())
+    return {"ms_per_call": ms, "score_sum": csum[0], "arcs_checksum": csum[1],
+            "checked_by": "tests/test_gpu_parity.py::test_cfg5_benched_workload_bit_exact_against_c_oracle (same workload, C oracle)", "us_per_frame": ms * 1e3 / T, "frames_per_s": B * T / (ms * 1e-3),
             "algorithmic_GBps": B * T * (4 * V + 16 * A + 4 * S) / (ms * 1e-3) / 1e9,
             "desc": f"cfg5 Viterbi + back-trace, synthetic TLG-like graph S={S} A={A}, B={B}, T={T}, V={V}, exact search, "
                     "includes the host-side label extraction of wf.best_path"}

@@ -172,6 +172,42 @@ def tot_and_grad(g, lp, T, output_beam=None, dtype=np.float64):
     return tot, grad
 
 
+def arc_posteriors(g, lp, T, dtype=np.float64):
+    """post[t, j] = exp(alpha_t[src] + x + beta_{t+1}[dst] - tot) for the j-th EMITTING arc (original arc order);
+    zeros when the utterance is infeasible.  The quantity waterfall/manual_ctc/prior.py:49-55 normalises per frame when
+    the graph is given one machine state per arc (oracle/graphs.py graph_to_trans_transform)."""
+    em, _ = _split(g)
+    src, dst = g["src"][em], g["dst"][em]
+    alpha, tot = forward(g, lp, T, True, dtype)
+    post = np.zeros((T, int(em.sum())), dtype=dtype)
+    if not np.isfinite(tot):
+        return post
+    beta = backward(g, lp, T, True, dtype)
+    for t in range(T):
+        x = arc_scores(g, lp[t]).astype(dtype)
+        with np.errstate(under="ignore"):
+            post[t] = np.exp(alpha[t, src] + x + beta[t + 1, dst] - tot)
+    return post
+
+
+def state_posteriors(g, lp, T, dtype=np.float64):
+    """log P(state s after consuming frame t) = alpha_{t+1}[s] + beta_{t+1}[s] - tot, [T, S] (prior.py:4-55 when machine
+    states are graph states); -inf where impossible."""
+    alpha, tot = forward(g, lp, T, True, dtype)
+    beta = backward(g, lp, T, True, dtype)
+    with np.errstate(invalid="ignore"):
+        out = alpha[1:T + 1] + beta[1:T + 1] - tot
+    return np.where(np.isnan(out), NEG_INF, out)
+
+
+def scale_graph(g, eta):
+    """The graph with every score multiplied by eta (eta-semiring of softmax_ctc.py:44-62: 1/eta * LSE(eta * x) is the
+    log semiring on scores scaled by eta)."""
+    h = dict(g)
+    h["score"] = (g["score"].astype(np.float64) * eta).astype(np.float32)
+    return h
+
+
 def viterbi(g, lp, T, dtype=np.float32):
     """Tropical best path. Returns (score, arcs) with arcs = T emitting arc ids + the final arc id.
 

@@ -732,3 +732,166 @@ def test_autograd_split_prezero_and_second_backward():
         np.testing.assert_allclose(loss.item(), want, rtol=TOT_RTOL)
         np.testing.assert_allclose(g1.cpu().numpy(), wgrad, atol=GRAD_ATOL)
         np.testing.assert_allclose(x.grad.cpu().numpy(), 2 * wgrad, atol=2 * GRAD_ATOL)
+
+
+# ---- round 2: reference-generated fixtures at realistic sizes; cfg4 / cfg5 at the benched sizes -------
+
+def _segs_of(z):
+    B = z["log_probs"].shape[0]
+    return np.stack([np.arange(B), np.zeros(B), z["input_lengths"]], 1).astype(np.int32)
+
+
+def _golden_fsa(z):
+    if "g_src" in z:
+        return util.graphs_to_fsa(util.golden_graphs(z))
+    V = z["log_probs"].shape[-1]
+    topo = wf.Topology("ctc", util.ctc_phones(V)) if V > 300 else wf.build_topology("ctc", util.ctc_phones(V))[0]
+    off = z["target_off"]
+    return wf.compile_ctc_k2_graphs(topo, [z["targets"][off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)])
+
+
+@pytest.mark.parametrize("name", ["manual_ctc_ctc_cfg2.npz", "manual_ctc_2state_cfg2.npz", "manual_ctc_ctc_v5001.npz"])
+def test_golden_config_sizes_from_reference_manual_ctc(name):
+    # the reference's own dense [B,T,S,V] forward-backward (fp32) at T = 500, L = 80 and at V = 5001
+    z = util.load_golden(name)
+    fsa = _golden_fsa(z)
+    loss, grad = run_hip(fsa, z["log_probs"], _segs_of(z), "none")
+    np.testing.assert_allclose(loss, z["loss_none"], rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, z["grad"], atol=GRAD_ATOL)
+    np.testing.assert_allclose(loss.sum(), z["loss_sum"], rtol=TOT_RTOL)
+    tot, fgrad = fused_logsum(fsa, z["log_probs"], _segs_of(z))
+    np.testing.assert_allclose(-tot, z["loss_none"], rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(fgrad, z["grad"], atol=GRAD_ATOL)
+
+
+@pytest.mark.parametrize("name", ["manual_ctc_ctc_cfg2.npz", "manual_ctc_ctc_v5001.npz"])
+def test_manual_ctc_dropin_at_config_sizes(name):
+    from waterfall_amd import manual_ctc
+    z = util.load_golden(name)
+    trans, transform, lens = _manual_ctc_inputs(z)
+    il = torch.from_numpy(z["input_lengths"])
+    x = torch.from_numpy(z["log_probs"]).to(DEV).requires_grad_(True)
+    loss = manual_ctc.ctc_loss(x, il, trans, lens, transform, reduction="sum")
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["loss_sum"], rtol=TOT_RTOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), z["grad"], atol=GRAD_ATOL)
+    x2 = torch.from_numpy(z["log_probs"]).to(DEV).requires_grad_(True)
+    l2 = manual_ctc.ctc_softmax(x2, il, trans, transform, lens, eta=float(z["eta"]), reduction="sum")
+    l2.backward()
+    np.testing.assert_allclose(l2.item(), z["eta_loss_sum"], rtol=TOT_RTOL)
+    np.testing.assert_allclose(x2.grad.cpu().numpy(), z["eta_grad"], atol=GRAD_ATOL)
+    al = manual_ctc.compute_align(x.detach(), il, trans, lens, transform).cpu().numpy()
+    for b in range(z["align"].shape[0]):        # the fixture keeps the alignment of the first utterance(s)
+        T, S = int(z["input_lengths"][b]), int(lens[b])
+        np.testing.assert_allclose(np.exp(al[b, :T, :S]), np.exp(z["align"][b, :T, :S]), atol=GRAD_ATOL)
+
+
+@pytest.mark.parametrize("topo", ["2state", "mmictc", "3state-skip", "2state_sil3"])
+def test_manual_ctc_dropin_eta_and_alignment_on_topologies(topo):
+    # softmax_ctc.py / prior.py outputs of the reference on composed non-CTC graphs (one machine state per arc)
+    from oracle import graphs as og
+    from waterfall_amd import manual_ctc
+    z = util.load_golden(f"manual_ctc_{topo}_eta_align.npz")
+    V = z["log_probs"].shape[-1]
+    mats = [og.graph_to_trans_transform(g, V) for g in util.golden_graphs(z)]
+    S = max(m[0].shape[0] for m in mats)
+    B = len(mats)
+    trans = np.full((B, S, S), og.FMIN, dtype=np.float32)
+    transform = np.full((B, S, V), og.FMIN, dtype=np.float32)
+    lens = np.zeros(B, dtype=np.int64)
+    for b, (t, f) in enumerate(mats):
+        s = t.shape[0]
+        trans[b, :s, :s] = t
+        transform[b, :s] = f
+        lens[b] = s
+    trans, transform, lens_t = torch.from_numpy(trans).to(DEV), torch.from_numpy(transform).to(DEV), torch.from_numpy(lens).to(DEV)
+    il = torch.from_numpy(z["input_lengths"])
+    x = torch.from_numpy(z["log_probs"]).to(DEV).requires_grad_(True)
+    loss = manual_ctc.ctc_loss(x, il, trans, lens_t, transform, reduction="sum")
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["loss_sum"], rtol=TOT_RTOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), z["grad"], atol=GRAD_ATOL)
+    x2 = torch.from_numpy(z["log_probs"]).to(DEV).requires_grad_(True)
+    l2 = manual_ctc.ctc_softmax(x2, il, trans, transform, lens_t, eta=float(z["eta"]), reduction="sum")
+    l2.backward()
+    np.testing.assert_allclose(l2.item(), z["eta_loss_sum"], rtol=TOT_RTOL)
+    np.testing.assert_allclose(x2.grad.cpu().numpy(), z["eta_grad"], atol=GRAD_ATOL)
+    al = manual_ctc.compute_align(x.detach(), il, trans, lens_t, transform).cpu().numpy()
+    for b in range(B):
+        T, Sb = int(z["input_lengths"][b]), int(lens[b])
+        # rows 1 .. Sb-2 are the arcs; the virtual start / end rows never hold mass after a frame
+        np.testing.assert_allclose(np.exp(al[b, :T, 1:Sb - 1]), np.exp(z["align"][b, :T, 1:Sb - 1]), atol=GRAD_ATOL)
+    # the graph itself (not its arc encoding) through graphloss
+    loss_g, grad_g = run_hip(util.graphs_to_fsa(util.golden_graphs(z)), z["log_probs"], _segs_of(z), "none")
+    np.testing.assert_allclose(loss_g, z["loss_none"], rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad_g, z["grad"], atol=GRAD_ATOL)
+
+
+def test_full_size_3state_skip_denominator_properties(oracle_lib):
+    # cfg4 (LS BPE-5k 3state-skip denominator: V=15001, S=10002, A=25002, fan-in(0)=10001), reduced batch / frames
+    c = util.random_case(778, "3state-skip", B=4, T=120, L=8, P=5000, den=True)
+    g0 = c["ographs"][0]
+    assert c["V"] == 15001 and g0["num_states"] == 10002 and int((g0["label"] >= 0).sum()) == 25001
+    loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
+    for b in range(4):
+        T = int(c["segs"][b, 2])
+        np.testing.assert_allclose(grad[b, :T].sum(-1), -1.0, atol=2e-3)
+        assert np.all(grad[b, T:] == 0)
+    tot_d, grad_d = util.c_oracle_batch(oracle_lib, c["ographs"][:2], c["lp"][:2], c["segs"][:2], gscale=[-1.0] * 2,
+                                        use_double=True, nthreads=2)
+    np.testing.assert_allclose(loss[:2], -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad[:2], grad_d, atol=GRAD_ATOL)
+    run = lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none")
+    lg, gg = _with_env({"WF_NO_LINBIG_SWEEP": "1"}, run)          # log-semiring sweep on the same batch
+    np.testing.assert_allclose(lg, loss, rtol=1e-6)
+    np.testing.assert_allclose(gg, grad, atol=2e-5)
+    l5, g5 = _with_env({"WF_FORCE_FALLBACK": "1"}, run)
+    np.testing.assert_allclose(l5, loss, rtol=1e-6)
+    np.testing.assert_allclose(g5, grad, atol=2e-5)
+    fwd = lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none", need_grad=False)[0]
+    assert np.array_equal(fwd(), loss)
+
+
+def test_full_size_3state_skip_numerator_against_c_oracle(oracle_lib):
+    # cfg4's numerator as bench.py times it (V=15001, L=64, T=500), 8 of the 32 utterances
+    c = _full_size("3state-skip", 5000, 64, False, B=8)
+    assert c["V"] == 15001
+    loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
+    tot_d, grad_d = util.c_oracle_batch(oracle_lib, c["ographs"], c["lp"], c["segs"], gscale=[-1.0] * 8,
+                                        use_double=True, nthreads=8)
+    np.testing.assert_allclose(loss, -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, grad_d, atol=GRAD_ATOL)
+    tot, fgrad = fused_logsum(c["fsa"], c["lp"], c["segs"])
+    np.testing.assert_allclose(-tot, -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(fgrad, grad_d, atol=GRAD_ATOL)
+
+
+def test_full_size_mmictc_numerator_against_c_oracle(oracle_lib):
+    c = _full_size("mmictc", 5000, 64, False, B=8)
+    assert c["V"] == 10001
+    loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
+    tot_d, grad_d = util.c_oracle_batch(oracle_lib, c["ographs"], c["lp"], c["segs"], gscale=[-1.0] * 8,
+                                        use_double=True, nthreads=8)
+    np.testing.assert_allclose(loss, -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, grad_d, atol=GRAD_ATOL)
+
+
+@pytest.mark.parametrize("S,T", [(100_000, 500), (1_000_000, 48)])
+def test_cfg5_benched_workload_bit_exact_against_c_oracle(oracle_lib, S, T):
+    # bench.py's cfg5 workload (same generator, seed, B = 8, V = 5001); S = 1e5 at the benched T = 500, S = 1e6 at reduced T
+    from waterfall_amd.synth import best_path_checksum, cfg5_workload
+    B = 8
+    g, fsa, lp, dense = cfg5_workload(torch.device(DEV), S, B, T, 5001)
+    out = wf.best_path(fsa, dense)
+    scores, arcs = out["scores"].cpu().numpy(), out["arcs"].cpu().numpy()
+    trop = wf.tot_scores(fsa, dense, log_semiring=False).cpu().numpy()
+    lp_h = lp.cpu().numpy()
+    want_s, want_a = np.zeros(B, dtype=np.float32), np.full((B, T + 1), -1, dtype=np.int32)
+    for i in range(B):
+        s, path = util.c_oracle_viterbi(oracle_lib, g, lp_h[i], T)
+        want_s[i] = s
+        want_a[i, :len(path)] = path
+    assert np.isfinite(want_s).all()
+    assert np.array_equal(scores, want_s) and np.array_equal(trop, want_s)
+    assert np.array_equal(arcs, want_a)
+    assert best_path_checksum(scores, arcs) == best_path_checksum(want_s, want_a)

@@ -57,6 +57,61 @@ def test_oracle_matches_reference_manual_ctc_on_topologies(topo):
     np.testing.assert_allclose(grad, z["grad"], atol=2e-5)
 
 
+# ---- round-2 fixtures: the reference's manual_ctc code at realistic sizes (T = 500, L = 80; V = 5001) and its
+# eta-semiring / alignment outputs on non-CTC topologies (tests/golden/make_golden.py make_round2) ----
+
+def _segs_of(z):
+    B = z["log_probs"].shape[0]
+    return np.stack([np.arange(B), np.zeros(B), z["input_lengths"]], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("name", ["manual_ctc_ctc_cfg2.npz", "manual_ctc_ctc_v5001.npz", "manual_ctc_2state_cfg2.npz"])
+def test_oracle_matches_reference_manual_ctc_at_config_sizes(name):
+    z = util.load_golden(name)
+    graphs = util.golden_graphs(z) if "g_src" in z else _ctc_graphs(z)
+    loss, grad = o.graphloss(graphs, z["log_probs"], _segs_of(z), None, "none")
+    # the reference accumulates 500 frames in fp32 (ctc.py:41-45); the oracle in fp64
+    np.testing.assert_allclose(loss, z["loss_none"], rtol=2e-5)
+    np.testing.assert_allclose(loss.sum(), z["loss_sum"], rtol=2e-5)
+    np.testing.assert_allclose(grad, z["grad"], atol=5e-4)   # measured 2.8e-4 at T = 500 (fp32 drift in the reference)
+    if "align" in z:
+        # prior.py:49-55 state posteriors of the first utterance(s).  The machine's 2L+1 states are the states of the
+        # graph that the manual_ctc drop-in's host conversion builds from (trans, transform) -- same state ids
+        from waterfall_amd import manual_ctc
+        V = z["log_probs"].shape[-1]
+        off = z["target_off"]
+        for b in range(z["align"].shape[0]):
+            tr, tf = og.ctc_trans_transform(z["targets"][off[b]:off[b + 1]].tolist(), V)
+            fsa = manual_ctc.matrices_to_fsa(torch.from_numpy(tr)[None], torch.tensor([tr.shape[0]]), torch.from_numpy(tf)[None])
+            g = fsa.as_oracle_graphs()[0]
+            T = int(z["input_lengths"][b])
+            sp = o.state_posteriors(g, z["log_probs"][b], T)
+            np.testing.assert_allclose(np.exp(sp[:, :tr.shape[0]]), np.exp(z["align"][b, :T, :tr.shape[0]]), atol=5e-4)
+
+
+@pytest.mark.parametrize("topo", ["2state", "mmictc", "3state-skip", "2state_sil3"])
+def test_oracle_matches_reference_eta_semiring_and_alignment_on_topologies(topo):
+    z = util.load_golden(f"manual_ctc_{topo}_eta_align.npz")
+    lp, lens = z["log_probs"], z["input_lengths"]
+    graphs = util.golden_graphs(z)
+    segs = _segs_of(z)
+    loss, grad = o.graphloss(graphs, lp, segs, None, "none")
+    np.testing.assert_allclose(loss, z["loss_none"], rtol=2e-5)
+    np.testing.assert_allclose(grad, z["grad"], atol=2e-5)
+    # softmax_ctc.py:44-62: 1/eta * LSE(eta x) = the log semiring on the scaled model; its gradient w.r.t. log_probs
+    # is minus the scaled model's posteriors (softmax_ctc.py:80-92)
+    eta = float(z["eta"])
+    l_eta, g_eta = o.graphloss([o.scale_graph(g, eta) for g in graphs], lp * np.float32(eta), segs, None, "none")
+    np.testing.assert_allclose(l_eta.sum() / eta, z["eta_loss_sum"], rtol=2e-5)
+    np.testing.assert_allclose(g_eta, z["eta_grad"], atol=2e-5)
+    # prior.py:49-55 on the arc encoding: row 1 + j of the machine = the j-th emitting arc
+    for b, g in enumerate(graphs):
+        T = int(lens[b])
+        post = o.arc_posteriors(g, lp[b], T)
+        n = post.shape[1]
+        np.testing.assert_allclose(np.exp(z["align"][b, :T, 1:1 + n]), post, atol=2e-5)
+
+
 def test_oracle_matches_torch_ctc_loss():
     # independent known answer: the reference treats F.ctc_loss as the same loss (models.py:212-216)
     z = util.load_golden("manual_ctc_ctc_medium.npz")

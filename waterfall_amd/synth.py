@@ -24,3 +24,28 @@ def synth_decoding_graph(seed, S, V, hubs=4, hub_fan_in=300):
     order = np.argsort(src, kind="stable")      # k2 keeps arcs sorted by source state
     return {"src": src[order].astype(np.int32), "dst": dst[order].astype(np.int32), "label": lab[order],
             "score": sc[order], "aux": lab[order].copy(), "num_states": S}
+
+
+def cfg5_workload(dev, S, B=8, T=500, V=5001, seed=777):
+    """BASELINE.md cfg5 as bench.py times it and tests/test_gpu_parity.py checks it: one synthetic TLG-like graph
+    (A = 3 S) shared by B utterances, log_softmax(randn * 3) drawn on the device.  Returns (graph dict, Fsa vector,
+    log_probs [B,T,V] on dev, DenseFsaVec)."""
+    import torch
+    from .fsa import DenseFsaVec, Fsa, create_fsa_vec
+    g = synth_decoding_graph(seed, S, V)
+    arcs = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
+    one = Fsa(arcs, g["aux"], [0, arcs.shape[0]], [g["num_states"]])
+    fsa = create_fsa_vec([one] * B)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=gen, device=dev) * 3.0, -1)
+    dense = DenseFsaVec(lp, torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32))
+    return g, fsa, lp, dense
+
+
+def best_path_checksum(scores, arcs):
+    """(sum of the fp32 best scores in fp64, a position-weighted sum of the arc ids mod 2^61-1): what bench.py prints
+    for cfg5 and the parity test recomputes from the oracle's paths."""
+    sc = float(np.asarray(scores, dtype=np.float64).sum())
+    a = np.asarray(arcs, dtype=np.int64)
+    w = (np.arange(a.size, dtype=np.int64).reshape(a.shape) % 1000003) + 1
+    return sc, int(((a + 2) * w % 2305843009213693951).sum() % 2305843009213693951)
