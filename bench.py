@@ -115,7 +115,7 @@ class Workload:
         self.gd = self.fsa.blob_dev(dev)
         n = C.c_size_t(0)
         lib = _lib.lib()
-        _lib.check(lib.wf_fb_workspace_bytes(_np(self.gh), _np(self.fsa.utt2fsa), _np(self.segs), B, V, 0, 1, C.byref(n)))
+        _lib.check(lib.wf_fb_workspace_bytes(_np(self.gh), _np(self.fsa.utt2fsa), _np(self.segs), B, B, V, 0, 1, C.byref(n)))
         self.ws_bytes = n.value
         self.ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
         self.frames = int(lens.sum())

@@ -27,7 +27,12 @@
  *     thread-local message.  No C++ exception crosses this boundary.
  *   - the library never allocates or frees device memory and keeps no pointer after returning:
  *     the caller allocates outputs and the workspace (size from wf_fb_workspace_bytes()).
- *   - device work is stream-ordered and asynchronous; no host synchronisation inside.
+ *   - device work is stream-ordered and asynchronous.  The per-call tables (a few KB) are staged in a
+ *     pinned ring owned by the calling thread's context and copied with one asynchronous copy; the host
+ *     waits only if the copy issued 8 calls earlier by the same thread has not finished yet.
+ *   - per host thread and device the library keeps a small context (two side streams, their events, the
+ *     pinned ring): created lazily on first use or by wf_init(), released by wf_shutdown().  It is the only
+ *     mutable state besides the thread-local error string; entry points are re-entrant across threads.
  *   - an utterance whose graph has no path of its length is NOT an error: tot = -inf, grad = 0.
  *
  * Graph layout (host side, k2's Fsa layout): arcs int32[A][4] = {src, dst, label, score_bits}
@@ -74,6 +79,16 @@ typedef struct {
 
 int wf_version(void);
 const char* wf_last_error(void);
+
+/* ---- set-up / tear-down (no counterpart in the reference: k2 owns its CUDA context implicitly) -----
+ * wf_init(): set-up for the calling host thread on the CURRENT device (idempotent): side streams + events, the
+ * pinned staging ring, kernel attributes.  Optional for every entry
+ * point (they do it lazily).  wf_shutdown(): waits for the side streams of the
+ * calling thread and destroys its contexts on all devices.
+ * wf_debug_reload_env(): the WF_* environment test hooks are read once per process; tests that change them call this. */
+int wf_init(void);
+int wf_shutdown(void);
+int wf_debug_reload_env(void);
 
 /* ---- graph preparation (host only, no GPU needed) ------------------------------------------
  * Builds the position-independent "prepared graph": per FSA the incoming-arc CSR (forward sweep),
@@ -129,8 +144,9 @@ int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int3
  * utt2fsa: host [B] FSA index used by utterance i, or NULL for the identity (B == G); a single
  * shared denominator topology (rnnp.py:91-92) is utt2fsa = {0,0,...}.
  * seg: host int32 [B][3] = {sequence index b, start frame, num frames} (models.py:256-258).     */
+/* num_seqs: the first dimension of log_probs (the value the compute calls receive): sizes the seq -> utterance map. */
 int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
-                          int32_t B, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes);
+                          int32_t B, int32_t num_seqs, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes);
 
 /* ---- log-semiring forward-backward: total scores and gradient (graph.py:61-66 + autograd) ---
  * log_probs: device fp32, element (b,t,v) at b*strideB + t*strideT + v.

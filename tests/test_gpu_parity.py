@@ -130,6 +130,24 @@ def test_ragged_segments_start_offsets_and_unused_sequences():
     assert np.all(grad[3] == 0) and np.all(grad[2, :5] == 0) and np.all(grad[2, 35:] == 0)
 
 
+def test_many_more_sequences_than_segments():
+    # DenseFsaVec allows log_probs to hold far more sequences than the segments name (N = 300, B = 3): the workspace is
+    # sized with the same num_seqs that the compute calls plan with
+    c = util.random_case(14, "ctc", B=3, T=25, L=3, P=5, ragged=False)
+    lp = np.log(np.full((300, 25, c["V"]), 1.0 / c["V"], dtype=np.float32))
+    segs = np.array([[299, 0, 25], [7, 2, 20], [150, 0, 25]], dtype=np.int32)
+    for i in range(3):
+        lp[segs[i, 0]] = c["lp"][i]
+    loss, grad = run_hip(c["fsa"], lp, segs, "none")
+    want, wgrad = o.graphloss(c["ographs"], lp, segs, None, "none")
+    np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+    tot, fgrad = fused_logsum(c["fsa"], lp, segs)
+    np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(fgrad, wgrad, atol=GRAD_ATOL)
+    assert np.count_nonzero(np.abs(fgrad).sum((1, 2))) == 3
+
+
 def test_empty_transcript_and_single_frame():
     topo, tokens = wf.build_topology("ctc", util.ctc_phones(6))
     fsa = wf.compile_ctc_k2_graphs(topo, [[], [3], [2, 2]])
@@ -303,7 +321,7 @@ def fused_logsum(fsa, lp, segs, gscale=-1.0):
     p = lambda t: C.c_void_p(t.data_ptr())
     npp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
     n = C.c_size_t(0)
-    _lib.check(lib.wf_fb_workspace_bytes(npp(gh), npp(fsa.utt2fsa), npp(segs), B, V, 0, 1, C.byref(n)))
+    _lib.check(lib.wf_fb_workspace_bytes(npp(gh), npp(fsa.utt2fsa), npp(segs), B, N, V, 0, 1, C.byref(n)))
     ws = torch.empty(n.value, dtype=torch.uint8, device=DEV)
     tot = torch.empty(B, dtype=torch.float32, device=DEV)
     grad = torch.full_like(x, 7.0)   # every element must be overwritten
@@ -316,9 +334,12 @@ def fused_logsum(fsa, lp, segs, gscale=-1.0):
 
 
 def _with_env(env, fn):
+    """Runs fn with the WF_* test hooks set: the library reads them once per process, wf_debug_reload_env re-reads."""
     import os
+    from waterfall_amd import _lib
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
+    _lib.lib().wf_debug_reload_env()
     try:
         return fn()
     finally:
@@ -327,6 +348,7 @@ def _with_env(env, fn):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        _lib.lib().wf_debug_reload_env()
 
 
 SWEEP_CASES = [
@@ -448,7 +470,7 @@ def test_output_beam_fused_entry_point_needs_the_flag():
     gh, gd = c["fsa"].blob_host(), c["fsa"].blob_dev(torch.device(DEV))
     n = C.c_size_t(0)
     npp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
-    _lib.check(lib.wf_fb_workspace_bytes(npp(gh), npp(c["fsa"].utt2fsa), npp(segs), 2, x.shape[2], _lib.WF_PRUNED, 1, C.byref(n)))
+    _lib.check(lib.wf_fb_workspace_bytes(npp(gh), npp(c["fsa"].utt2fsa), npp(segs), 2, 2, x.shape[2], _lib.WF_PRUNED, 1, C.byref(n)))
     ws = torch.empty(n.value, dtype=torch.uint8, device=DEV)
     tot = torch.empty(2, dtype=torch.float32, device=DEV)
     grad = torch.empty_like(x)

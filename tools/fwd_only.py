@@ -10,7 +10,7 @@ wl = bench.Workload(sys.argv[1] if len(sys.argv) > 1 else "cfg3_ctc_bpe5k_num", 
 lib = _lib.lib()
 st = torch.cuda.current_stream(dev).cuda_stream
 n = C.c_size_t(0)
-_lib.check(lib.wf_fb_workspace_bytes(bench._np(wl.gh), bench._np(wl.fsa.utt2fsa), bench._np(wl.segs), wl.B, wl.V, 0, 0, C.byref(n)))
+_lib.check(lib.wf_fb_workspace_bytes(bench._np(wl.gh), bench._np(wl.fsa.utt2fsa), bench._np(wl.segs), wl.B, wl.B, wl.V, 0, 0, C.byref(n)))
 wl.ws_bytes = max(wl.ws_bytes, n.value)
 wl.ws = torch.empty(wl.ws_bytes, dtype=torch.uint8, device=dev)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

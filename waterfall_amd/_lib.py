@@ -48,9 +48,10 @@ _SIGS = {
     "wf_topo_index_words": (C.c_int, [_i32, _i32, C.POINTER(C.c_int64)]),
     "wf_topo_index_build": (C.c_int, [_p, _p, _i32, _i32, _p]),
     "wf_compose_linear_batch": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _i32, _p, _p, C.c_int64, _p, _p]),
-    "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),
-    "wf_fb_logsum": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, C.c_float, _u32,
-                               _p, _p, _p, _p, _sz, _p]),
+    "wf_init": (C.c_int, []),
+    "wf_shutdown": (C.c_int, []),
+    "wf_debug_reload_env": (C.c_int, []),
+    "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),
     "wf_fb_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, _u32,
                                  _p, _p, _p, _p, _sz, _p]),
     "wf_state_posteriors": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _u32, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),

@@ -30,6 +30,8 @@
 
 #include <vector>
 
+#include <utility>
+
 #include "../../include/wf_dwfst.h"
 #include "wf_internal.h"
 
@@ -3035,8 +3037,41 @@ struct RegCfg {
 };
 RegCfg lin_config(const Plan& P);
 size_t sweep_lds_bytes(const Plan& P, size_t acc_bytes);
-int env_int(const char* name, int dflt);
 constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where nothing else fits, until measured otherwise
+// Test / measurement hooks (environment variables WF_*): read ONCE, at the first call of the process, and again only
+// when a test calls wf_debug_reload_env() after changing them -- no getenv on the production path.
+struct Hooks {
+    int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
+        zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache,
+        post_profile, sweep_profile, quad_r, no_fused_gather, no_post_check;
+};
+Hooks g_hooks;
+bool g_hooks_loaded = false;
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+void load_hooks() {
+    Hooks h{};
+    h.no_band = env_int("WF_NO_BAND_SWEEP", 0); h.no_gen = env_int("WF_NO_GEN_SWEEP", 0);
+    h.no_lin = env_int("WF_NO_LIN_SWEEP", 0); h.no_linbig = env_int("WF_NO_LINBIG_SWEEP", 0);
+    h.no_reg = env_int("WF_NO_REG_SWEEP", 0); h.no_wave = env_int("WF_NO_WAVE_SWEEP", 0);
+    h.no_fwd_via_fb = env_int("WF_NO_FWD_VIA_FB", 0); h.no_gather_small = env_int("WF_NO_GATHER_SMALL", 0);
+    h.no_post_small = getenv("WF_NO_POST_SMALL") != nullptr; h.no_overlap = getenv("WF_NO_OVERLAP") != nullptr;
+    h.zero_memset = getenv("WF_ZERO_MEMSET") != nullptr; h.zero_blocks = env_int("WF_ZERO_BLOCKS", 0);
+    h.force_fallback = env_int("WF_FORCE_FALLBACK", 0); h.big_min_s = env_int("WF_BIG_MIN_S", kBigMinStates);
+    h.no_shared_big = env_int("WF_NO_SHARED_BIG", 0); h.post_big_min_s = env_int("WF_POST_BIG_MIN_S", 4096);
+    h.sweep_ablate = env_int("WF_SWEEP_ABLATE", 0); h.no_arc_cache = env_int("WF_NO_ARC_CACHE", 0);
+    h.post_profile = env_int("WF_POST_PROFILE", 0); h.sweep_profile = env_int("WF_SWEEP_PROFILE", 0);
+    h.quad_r = env_int("WF_QUAD_R", 0);
+    h.no_fused_gather = env_int("WF_NO_FUSED_GATHER", 0); h.no_post_check = env_int("WF_NO_POST_CHECK", 0);
+    g_hooks = h;
+    g_hooks_loaded = true;
+}
+inline const Hooks& hk() {
+    if (!g_hooks_loaded) load_hooks();
+    return g_hooks;
+}
 struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; bool gen = false; };
 BandSel band_config(const Plan& P);
 bool linbig_config(const Plan& P);
@@ -3108,7 +3143,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     P->off_tot2 = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
     // graphs whose sweep state does not fit the LDS (or, test hook, with at least WF_BIG_MIN_S states): per-frame launches
-    P->big = sweep_lds_bytes(*P, acc_bytes) > kLdsBudget || P->smax >= env_int("WF_BIG_MIN_S", kBigMinStates);
+    P->big = sweep_lds_bytes(*P, acc_bytes) > kLdsBudget || P->smax >= hk().big_min_s;
     if (mode == 0) {
         if (P->big && pruned)
             return wf_fail(WF_EUNSUPPORTED, "output_beam pruning is not available for graphs beyond the LDS-resident sweeps (%d states)", P->smax);
@@ -3134,7 +3169,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     } else if (mode == 2) {
         P->off_bp = o; o = align_up(o + sizeof(int32_t) * (size_t)nab, 256);
     }
-    if (mode != 0 && P->big && P->one_fsa && B >= 2 && !env_int("WF_NO_SHARED_BIG", 0)) {
+    if (mode != 0 && P->big && P->one_fsa && B >= 2 && !hk().no_shared_big) {
         P->shared = true;
         const size_t groups = (size_t)(B + kNB - 1) / kNB;
         P->off_big = o; o = align_up(o + 2 * acc_bytes * groups * (size_t)P->smax * kNB, 256);
@@ -3165,29 +3200,102 @@ int tm_record(int i, hipStream_t st) {
     return WF_OK;
 }
 
-// side stream for work that can overlap the latency-bound sweeps (one per device, per host thread)
+constexpr int kMaxDevices = 16;
+
+// Per host thread and device: side streams for work that can overlap the latency-bound sweeps, their events, and a
+// ring of pinned staging slots for the per-call tables (so that the host-to-device copy of a call is a true
+// asynchronous copy from memory that outlives the call; a slot is reused only after the copy that read it finished).
+constexpr int kRingSlots = 8;
+constexpr size_t kRingSlotInit = 64 * 1024;
 struct Side {
     hipStream_t stream = nullptr, stream2 = nullptr;   // zero-fill | backward direction of the big-graph sweep
     hipEvent_t fork = nullptr, join = nullptr, fork2 = nullptr, join2 = nullptr;
     bool fill_attr = false;
+    unsigned char* ring = nullptr;   // pinned, kRingSlots x slot_bytes
+    size_t slot_bytes = 0;
+    hipEvent_t ring_ev[kRingSlots] = {};
+    bool ring_used[kRingSlots] = {};
+    int ring_next = 0;
+    void* scratch_ptr = nullptr;
+    std::vector<std::pair<const void*, int>> lds_attr;   // kernels whose dynamic-LDS limit was raised on this device
 };
-thread_local Side g_side[16];
-int side_get(Side** out) {
+thread_local Side g_side[kMaxDevices];
+
+int ring_alloc(Side& s, size_t slot_bytes) {
+    if (s.ring) {
+        for (int i = 0; i < kRingSlots; ++i)
+            if (s.ring_used[i]) { HIP_TRY(hipEventSynchronize(s.ring_ev[i])); s.ring_used[i] = false; }
+        HIP_TRY(hipHostFree(s.ring));
+        s.ring = nullptr;
+    }
+    HIP_TRY(hipHostMalloc((void**)&s.ring, kRingSlots * slot_bytes, hipHostMallocDefault));
+    s.slot_bytes = slot_bytes;
+    return WF_OK;
+}
+
+// create = false: the allocation-free entry point; the context must exist already (wf_init)
+int side_get(Side** out, bool create = true) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return wf_fail(WF_EUNSUPPORTED, "device index %d", dev);
+    if (dev < 0 || dev >= kMaxDevices) return wf_fail(WF_EUNSUPPORTED, "device index %d", dev);
     Side& s = g_side[dev];
     if (!s.stream) {
+        if (!create) return wf_fail(WF_EINVAL, "wf_init() has not been called by this thread on device %d", dev);
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s.fork2, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.join2, hipEventDisableTiming));
+        for (auto& e : s.ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        int rc = ring_alloc(s, kRingSlotInit);
+        if (rc) return rc;
     }
     *out = &s;
     return WF_OK;
 }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, thread) instead of on every launch
+int ensure_lds(const void* fn, size_t bytes) {
+    if (bytes <= 48 * 1024) return WF_OK;
+    Side* s = nullptr;
+    int rc = side_get(&s);
+    if (rc) return rc;
+    for (auto& e : s->lds_attr)
+        if (e.first == fn) {
+            if (e.second >= (int)bytes) return WF_OK;
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            e.second = (int)bytes;
+            return WF_OK;
+        }
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    s->lds_attr.emplace_back(fn, (int)bytes);
+    return WF_OK;
+}
+
+// Makes the caller's stream wait for whatever was forked to a side stream, on EVERY exit path of an entry point
+// (an early error return must not leave side-stream work running on memory the caller is about to release).
+struct ForkGuard {
+    hipStream_t st;
+    hipStream_t side = nullptr;
+    hipEvent_t join = nullptr;
+    bool recorded = false, joined = false;
+    explicit ForkGuard(hipStream_t s) : st(s) {}
+    void fork(hipStream_t side_stream, hipEvent_t join_event) { side = side_stream; join = join_event; recorded = false; joined = false; }
+    int record() { if (side && !recorded) { HIP_TRY(hipEventRecord(join, side)); recorded = true; } return WF_OK; }
+    int wait() {
+        if (!side || joined) return WF_OK;
+        int rc = record();
+        if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(st, join, 0));
+        joined = true;
+        return WF_OK;
+    }
+    ~ForkGuard() { (void)wait(); }
+};
+
+constexpr int kFillLds = 84 * 1024;   // see the zero-fill launch in fb_logsum_impl
+int ensure_band_lds();
 
 struct SweepCfg {
     int threads, chunk, kpad, smax, arcs_words, hcap;
@@ -3241,18 +3349,20 @@ int launch_big(const Plan& P, BigArgs a, int B, hipStream_t st) {
     a.nlb = (P.smax + 255) / 256;
     hipLaunchKernelGGL((big_init_kernel<Acc, TROP>), dim3(std::min(a.nlb, 1024), B), dim3(256), 0, st, a);
     Side* side = nullptr;
+    ForkGuard guard(st);
     if (a.beta) {
         int rc = side_get(&side);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(side->fork2, st));
         HIP_TRY(hipStreamWaitEvent(side->stream2, side->fork2, 0));
+        guard.fork(side->stream2, side->join2);
         const dim3 gridb(a.nlb + P.nheavy_out_max, B);
         BigArgs b = a;
         for (int t = P.Tlong - 1; t >= 0; --t) {
             b.t = t;
             hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP, 1>), gridb, dim3(256), 0, side->stream2, b);
         }
-        HIP_TRY(hipEventRecord(side->join2, side->stream2));
+        if ((rc = guard.record())) return rc;
     }
     const dim3 grid(a.nlb + P.nheavy_in_max, B);
     for (int t = 0; t < P.Tlong; ++t) {
@@ -3261,8 +3371,7 @@ int launch_big(const Plan& P, BigArgs a, int B, hipStream_t st) {
     }
     hipLaunchKernelGGL((big_final_kernel<Acc, Sum, TROP>), dim3(B), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
-    if (side) HIP_TRY(hipStreamWaitEvent(st, side->join2, 0));
-    return WF_OK;
+    return guard.wait();
 }
 
 // big-graph forward sweep of a batch that shares one graph (Plan::shared)
@@ -3291,8 +3400,8 @@ int launch_big_shared(const Plan& P, unsigned char* ws, const BigArgs& a, int B,
 template <typename Acc, typename Sum, int MODE>
 int launch_sweep(const SweepCfg& c, const SweepArgs& a_, int B, hipStream_t st) {
     SweepArgs a = a_;
-    a.ablate |= env_int("WF_SWEEP_ABLATE", 0);
-    if (env_int("WF_NO_ARC_CACHE", 0)) a.ablate |= 16;   // test hook: streamed arcs re-read in every frame
+    a.ablate |= hk().sweep_ablate;
+    if (hk().no_arc_cache) a.ablate |= 16;   // test hook: streamed arcs re-read in every frame
     const int ndir = (MODE == M_FB || MODE == M_FB_MAX) ? 2 : 1;
     dim3 grid(B * ndir), block(c.threads);
     if (c.lds > kLdsBudget)
@@ -3301,8 +3410,7 @@ int launch_sweep(const SweepCfg& c, const SweepArgs& a_, int B, hipStream_t st) 
 #define WF_LAUNCH(AL, ES)                                                                            \
     do {                                                                                             \
         auto k = sweep_kernel<Acc, Sum, MODE, AL, ES>;                                                    \
-        if (c.lds > 48 * 1024)                                                                       \
-            HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds)); \
+        { int rc_ = ensure_lds((const void*)k, c.lds); if (rc_) return rc_; }                         \
         hipLaunchKernelGGL(k, grid, block, c.lds, st, a);                                            \
     } while (0)
     if (c.arcs_lds && c.estage) WF_LAUNCH(true, true);
@@ -3320,27 +3428,22 @@ int launch_sweep_masked(const SweepCfg& c, const SweepArgs& a, int B, hipStream_
         return wf_fail(WF_EUNSUPPORTED, "graph too large for the LDS-resident sweep: %d states need %zu B of LDS (> %zu)",
                        c.smax, c.lds, kLdsBudget);
     auto k = sweep_kernel<double, float, M_FB, false, false, true>;
-    if (c.lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds));
+    { int rc_ = ensure_lds((const void*)k, c.lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(k, dim3(B * 2), dim3(c.threads), c.lds, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
 
 // ---- register-resident quad sweep: eligibility and launch
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 RegCfg reg_config(const Plan& P, bool both_dirs) {
     RegCfg c;
-    const int no_reg = env_int("WF_NO_REG_SWEEP", 0);   // test hook, read per call
+    const int no_reg = hk().no_reg;   // test hook
     if (no_reg) return c;
     if (!P.arcs_lds_ok || P.smax > kMaxThreads || !P.reg_ok_in || (both_dirs && !P.reg_ok_out)) return c;
     // four lanes per state; R states per quad once 4*S exceeds the workgroup
     c.R = P.smax * 4 <= kMaxThreads ? 1 : (P.smax * 2 <= kMaxThreads ? 2 : 4);
-    static const int force_r = env_int("WF_QUAD_R", 0);
+    const int force_r = hk().quad_r;
     if (force_r == 2 || force_r == 4) c.R = std::max(c.R, force_r);
     c.threads = std::max(64, (int)align_up(4 * (size_t)((P.smax + c.R - 1) / c.R), 64));
     const int od = std::max(P.over_deg_in, both_dirs ? P.over_deg_out : 0);
@@ -3356,7 +3459,7 @@ RegCfg reg_config(const Plan& P, bool both_dirs) {
 // direction has <= WF_REG_DEG arcs; the exceptional state's arcs fit HD <= 2 per lane
 RegCfg lin_config(const Plan& P) {
     RegCfg c;
-    const int no_lin = env_int("WF_NO_LIN_SWEEP", 0);   // test hook, read per call
+    const int no_lin = hk().no_lin;   // test hook
     if (no_lin) return c;
     if (P.smax > kMaxThreads || !P.reg_ok_in || !P.reg_ok_out) return c;
     c.threads = std::max(64, (int)align_up(P.smax, 64));
@@ -3376,7 +3479,7 @@ int lin_group(const RegCfg& c) { return c.threads <= 256 ? 8 : 4; }
 // kLBSlot * 1024 states with at most kLBHeavy heavy states, when neither the banded nor the lane-per-state sweep applies
 size_t linbig_lds(const Plan& P) { return (size_t)kLBHeavy * 16 * 8 + 32 * 4 + 2 * ((size_t)align_up(P.smax, 4) + 4) * 4 + align_up(P.kmax, 4) * 4; }
 bool linbig_config(const Plan& P) {
-    if (env_int("WF_NO_LIN_SWEEP", 0) == 1 || env_int("WF_NO_LINBIG_SWEEP", 0)) return false;   // test hooks, read per call (WF_NO_LIN_SWEEP=2: only the lane-per-state kernel is off)
+    if (hk().no_lin == 1 || hk().no_linbig) return false;   // test hooks (WF_NO_LIN_SWEEP=2: only the lane-per-state kernel is off)
     if (band_config(P).ok || lin_config(P).ok) return false;
     return P.band_we && P.smax <= kLBSlot * kMaxThreads && P.kmax <= kLBSlot * kMaxThreads && P.hmax <= kLBHeavy &&
            linbig_lds(P) <= kLdsBudget;
@@ -3393,8 +3496,7 @@ void lin_grp_lag(const Plan& P, int* grp, int* lag) {
 int launch_sweep_linbig(const Plan& P, SweepArgs a, int B, hipStream_t st) {
     a.smax = (int)align_up(P.smax, 4);
     const size_t lds = linbig_lds(P);
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)sweep_linbig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc_ = ensure_lds((const void*)sweep_linbig_kernel, lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(sweep_linbig_kernel, dim3(B * 2), dim3(kMaxThreads), lds, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
@@ -3403,13 +3505,13 @@ int launch_sweep_linbig(const Plan& P, SweepArgs a, int B, hipStream_t st) {
 // banded wave sweep: every graph of the call is banded and fits one wavefront; picks the instantiation
 BandSel band_config(const Plan& P) {
     BandSel b;
-    const int no_band = env_int("WF_NO_BAND_SWEEP", 0);   // test hook, read per call
+    const int no_band = hk().no_band;   // test hook
     if (no_band || P.band_sn < 1 || P.kmax >= kBandKP) return b;
     b.grp = kBandC;
     if (P.band_bw < 0) {
         // no banded order (a cycle besides self-loops: denominators): the general-graph mode of the wave kernel, for
         // graphs of at most 64 non-final states with <= WF_REG_DEG arcs per state but for one state of up to 64
-        if (env_int("WF_NO_GEN_SWEEP", 0) || P.band_sn > 64 || !P.reg_ok_in || !P.reg_ok_out || P.over_deg_in > 64 || P.over_deg_out > 64)
+        if (hk().no_gen || P.band_sn > 64 || !P.reg_ok_in || !P.reg_ok_out || P.over_deg_in > 64 || P.over_deg_out > 64)
             return b;
         b.gen = true;
         b.R = b.BW = b.M = 1;
@@ -3429,15 +3531,14 @@ BandSel band_config(const Plan& P) {
 template <int R, int BW, int MM, bool WE, bool GEN = false>
 int launch_band_one(const SweepArgs& a, int B, hipStream_t st) {
     auto k = sweep_band_kernel<R, BW, MM, WE, GEN>;
-    if (kBandLds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds));
+    { int rc_ = ensure_lds((const void*)k, kBandLds); if (rc_) return rc_; }
     hipLaunchKernelGGL(k, dim3(B * 2), dim3(128), kBandLds, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
 
 int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st) {
-    static const int prof = env_int("WF_SWEEP_PROFILE", 0);
+    const int prof = hk().sweep_profile;
     a.ablate = prof;
     if (b.gen) return b.we ? launch_band_one<1, 1, 1, true, true>(a, B, st) : launch_band_one<1, 1, 1, false, true>(a, B, st);
 #define WF_BAND_CASE(RR, WW)                                                                     \
@@ -3452,15 +3553,28 @@ int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st) {
     return wf_fail(WF_EUNSUPPORTED, "internal: no banded sweep for R=%d BW=%d", b.R, b.BW);
 }
 
+// wf_init: the dynamic-LDS attribute of every banded instantiation, so that a later launch finds it set
+int ensure_band_lds() {
+    int rc = 0;
+#define WF_BAND_ATTR(...) if ((rc = ensure_lds((const void*)sweep_band_kernel<__VA_ARGS__>, kBandLds))) return rc
+    WF_BAND_ATTR(1, 1, 1, true, true); WF_BAND_ATTR(1, 1, 1, false, true);
+    WF_BAND_ATTR(2, 2, 1, true); WF_BAND_ATTR(2, 2, 1, false); WF_BAND_ATTR(2, 2, 2, false);
+    WF_BAND_ATTR(3, 2, 1, true); WF_BAND_ATTR(3, 2, 1, false); WF_BAND_ATTR(3, 2, 2, false);
+    WF_BAND_ATTR(4, 2, 1, true); WF_BAND_ATTR(4, 2, 1, false); WF_BAND_ATTR(4, 2, 2, false);
+    WF_BAND_ATTR(4, 4, 1, true); WF_BAND_ATTR(4, 4, 1, false); WF_BAND_ATTR(4, 4, 2, false);
+#undef WF_BAND_ATTR
+    return WF_OK;
+}
+
 int launch_sweep_lin(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
     dim3 grid(B * 2), block(c.threads);
     a.smax = c.smax;
-    static const int prof = env_int("WF_SWEEP_PROFILE", 0);
+    const int prof = hk().sweep_profile;
     a.ablate = prof;   // bit 8: print cycles per step; bits 1/2/4: ablations (row stores / ring refills / rescale) for timing only
     // two register budgets: workgroups of <= 256 lanes may use up to 512 VGPRs per lane
 #define WF_LAUNCH_LIN(HH)                                                                             \
     do {                                                                                              \
-        if (c.threads == 64 && !env_int("WF_NO_WAVE_SWEEP", 0)) hipLaunchKernelGGL((sweep_lin_kernel<HH, 256, true>), grid, block, c.lds, st, a); \
+        if (c.threads == 64 && !hk().no_wave) hipLaunchKernelGGL((sweep_lin_kernel<HH, 256, true>), grid, block, c.lds, st, a); \
         else if (c.threads <= 256) hipLaunchKernelGGL((sweep_lin_kernel<HH, 256>), grid, block, c.lds, st, a); \
         else hipLaunchKernelGGL((sweep_lin_kernel<HH, kMaxThreads>), grid, block, c.lds, st, a);        \
     } while (0)
@@ -3476,7 +3590,7 @@ template <int MODE>
 int launch_sweep_quad(const RegCfg& c, SweepArgs a, int B, hipStream_t st) {
     dim3 grid(B), block(c.threads);
     a.smax = c.smax;
-    static const int prof = env_int("WF_SWEEP_PROFILE", 0);
+    const int prof = hk().sweep_profile;
     a.ablate = prof ? 8 : 0;
 #define WF_LAUNCH_QUAD(RR, HH) hipLaunchKernelGGL((sweep_quad_kernel<MODE, RR, HH>), grid, block, c.lds, st, a)
 #define WF_LAUNCH_QUAD_R(RR)                       \
@@ -3504,7 +3618,7 @@ int plan_fb(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, 
             bool dbl, bool pruned, Plan* P, bool* fwd_via_fb) {
     *fwd_via_fb = false;
     int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, rows ? 0 : 1, P, dbl, pruned);
-    if (rc || rows || dbl || P->smax < 4096 || P->big || env_int("WF_NO_FWD_VIA_FB", 0)) return rc;
+    if (rc || rows || dbl || P->smax < 4096 || P->big || hk().no_fwd_via_fb) return rc;
     Plan P0;
     if (make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P0, false, false) == WF_OK && P0.linbig) {
         *P = P0;
@@ -3514,13 +3628,13 @@ int plan_fb(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, 
 }
 
 extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
-                                     int32_t B, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes) {
+                                     int32_t B, int32_t num_seqs, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes) {
     if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
     Plan P;
-    int maxseq = 0;
-    if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
+    // the seq -> utterance map is sized by num_seqs, exactly as the compute calls plan it (a log_probs tensor may hold
+    // many more sequences than the segments name)
     bool fwd_via_fb = false;
-    int rc = plan_fb(graph_host, utt2fsa, seg, B, V, maxseq, need_grad || (flags & (WF_KEEP_AB | WF_PRUNED)),
+    int rc = plan_fb(graph_host, utt2fsa, seg, B, V, num_seqs, need_grad || (flags & (WF_KEEP_AB | WF_PRUNED)),
                      (flags & WF_DOUBLE_ACC) != 0, (flags & WF_PRUNED) != 0, &P, &fwd_via_fb);
     if (rc) return rc;
     *bytes = P.total + 256;
@@ -3541,20 +3655,32 @@ extern "C" int wf_viterbi_workspace_bytes(const void* graph_host, const int32_t*
 }
 
 namespace {
-// copies the per-call tables into the workspace and launches the gather when needed
-int upload_tables(const Plan& P, unsigned char* ws, const int32_t* seq2utt, int num_seqs, hipStream_t st) {
-    // one host-to-device copy for both tables (each copy costs ~4 us of stream time): the workspace regions
-    // are adjacent (off_utt, then off_seq2utt), so stage them in one buffer with the same layout
+// Copies the per-call tables (utterance table, then the seq -> utterance map: adjacent workspace regions, one copy)
+// into the workspace: staged in a pinned ring slot owned by this thread's context, so the copy is asynchronous
+// and its source outlives the call.  may_grow = false (allocation-free entry point): a table larger than a slot is an
+// error instead of a reallocation.
+int upload_tables(const Plan& P, unsigned char* ws, const int32_t* seq2utt, int num_seqs, hipStream_t st, bool may_grow = true) {
     const size_t utt_bytes = sizeof(int64_t) * P.utt.size();
-    if (!seq2utt) {
-        HIP_TRY(hipMemcpyAsync(ws + P.off_utt, P.utt.data(), utt_bytes, hipMemcpyHostToDevice, st));
-        return WF_OK;
+    const size_t span = seq2utt ? (P.off_seq2utt - P.off_utt) + sizeof(int32_t) * (size_t)num_seqs : utt_bytes;
+    Side* s = nullptr;
+    int rc = side_get(&s, may_grow);
+    if (rc) return rc;
+    if (span > s->slot_bytes) {
+        if (!may_grow) return wf_fail(WF_ENOSPC, "per-call tables need %zu B but a staging slot holds %zu B (B or num_seqs too large for the allocation-free entry point)", span, s->slot_bytes);
+        if ((rc = ring_alloc(*s, align_up(span * 2, 4096)))) return rc;
     }
-    const size_t span = (P.off_seq2utt - P.off_utt) + sizeof(int32_t) * (size_t)num_seqs;
-    std::vector<unsigned char> stage(span, 0);
-    memcpy(stage.data(), P.utt.data(), utt_bytes);
-    memcpy(stage.data() + (P.off_seq2utt - P.off_utt), seq2utt, sizeof(int32_t) * (size_t)num_seqs);
-    HIP_TRY(hipMemcpyAsync(ws + P.off_utt, stage.data(), span, hipMemcpyHostToDevice, st));
+    const int slot = s->ring_next;
+    s->ring_next = (slot + 1) % kRingSlots;
+    if (s->ring_used[slot]) HIP_TRY(hipEventSynchronize(s->ring_ev[slot]));   // the copy issued kRingSlots calls ago
+    unsigned char* stage = s->ring + (size_t)slot * s->slot_bytes;
+    memcpy(stage, P.utt.data(), utt_bytes);
+    if (seq2utt) {
+        memset(stage + utt_bytes, 0, (P.off_seq2utt - P.off_utt) - utt_bytes);
+        memcpy(stage + (P.off_seq2utt - P.off_utt), seq2utt, sizeof(int32_t) * (size_t)num_seqs);
+    }
+    HIP_TRY(hipMemcpyAsync(ws + P.off_utt, stage, span, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(s->ring_ev[slot], st));
+    s->ring_used[slot] = true;
     return WF_OK;
 }
 
@@ -3573,7 +3699,7 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
         GatherLinArgs g{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), lp, strideB, strideT,
                         (float*)(ws + P.off_E), (double*)(ws + P.off_P), (double*)(ws + P.off_cmax),
                         (int32_t*)(ws + P.off_flag), P.linbig ? (float*)(ws + P.off_P) : nullptr};
-        if (!P.linbig && P.kmax <= 128 && !env_int("WF_NO_GATHER_SMALL", 0))
+        if (!P.linbig && P.kmax <= 128 && !hk().no_gather_small)
             hipLaunchKernelGGL(gather_lin_small_kernel, dim3((std::max(P.Tlong, 1) + kGFR - 1) / kGFR, P.B), dim3(64), 0, st, g);
         else
             hipLaunchKernelGGL(gather_lin_kernel, dim3(std::max(P.Tlong, 1), P.B), dim3(64), 0, st, g);
@@ -3600,7 +3726,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
         q.lin = P.lin ? grp : 0;
         q.lag = lag;
     }
-    q.prof = env_int("WF_POST_PROFILE", 0);
+    q.prof = hk().post_profile;
     q.ctot2 = (const double*)(ws + P.off_ctot2); q.cmax = (const double*)(ws + P.off_cmax);
     q.flag = (const int32_t*)(ws + P.off_flag);
     if (P.pruned) { q.mA = (const float*)(ws + P.off_mA); q.mB = (const float*)(ws + P.off_mB); q.thr = (const float*)(ws + P.off_thr); }
@@ -3618,7 +3744,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     size_t lds = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
     // pre-zeroed rows (some graph compact: the side-stream fill covered the whole box), or only graphs whose columns are the
     // labels (the kernel zeroes the few columns it does not write)
-    if (P.lin && (skip_zero || !P.any_compact) && !getenv("WF_NO_POST_SMALL") && P.amax >= 1 && P.amax <= 128 * 8 && P.smax <= 64 * 8 &&
+    if (P.lin && (skip_zero || !P.any_compact) && !hk().no_post_small && P.amax >= 1 && P.amax <= 128 * 8 && P.smax <= 64 * 8 &&
         P.kmax <= 64 * 8) {
         q.ecap = (int)align_up(P.kmax, 4);
         q.acap = (int)align_up(P.amax, 4);
@@ -3636,7 +3762,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     }
     // rows beyond the LDS, or long enough that staging them costs more than gathering per arc (measured on cfg4's
     // denominators, S = 10 002: 2.4 ms against 3.9 ms): gather from memory.  Log-domain, unpruned rows only.
-    if (lds > kLdsBudget || ((!P.lin || P.linbig) && !P.pruned && P.smax >= env_int("WF_POST_BIG_MIN_S", 4096))) {
+    if (lds > kLdsBudget || ((!P.lin || P.linbig) && !P.pruned && P.smax >= hk().post_big_min_s)) {
         if (P.pruned) return wf_fail(WF_EUNSUPPORTED, "internal: post_big_kernel needs unpruned rows");
         hipLaunchKernelGGL(post_big_kernel, dim3(Tmax, num_seqs), dim3(256), 0, st, q);
         HIP_TRY(hipGetLastError());
@@ -3650,7 +3776,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     if (small) {
         hipLaunchKernelGGL(post_kernel<true>, grid, block, lds, st, q);
     } else {
-        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)post_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_ = ensure_lds((const void*)post_kernel<false>, lds); if (rc_) return rc_; }
         hipLaunchKernelGGL(post_kernel<false>, grid, block, lds, st, q);
     }
     HIP_TRY(hipGetLastError());
@@ -3658,12 +3784,15 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
 }
 }  // namespace
 
-extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
-                            const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
-                            int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,
-                            uint32_t flags, const float* grad_scale, float* tot, float* grad,
-                            void* workspace, size_t workspace_bytes, void* stream) {
-    if (!graph_dev || !log_probs || !tot || !workspace) return wf_fail(WF_EINVAL, "wf_fb_logsum: null pointer");
+namespace {
+// use_scratch: the allocation-free entry point -- the workspace is this device's static scratch array, nothing may
+// be allocated (the thread's context must exist: wf_init)
+int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                   const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
+                   int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,
+                   uint32_t flags, const float* grad_scale, float* tot, float* grad,
+                   void* workspace, size_t workspace_bytes, void* stream, bool use_scratch) {
+    if (!graph_dev || !log_probs || !tot || (!workspace && !use_scratch) || !seg) return wf_fail(WF_EINVAL, "wf_fb_logsum: null pointer");
     const bool pruned = output_beam > 0 && !std::isinf(output_beam);
     if (pruned != ((flags & WF_PRUNED) != 0))
         return wf_fail(WF_EINVAL, "wf_fb_logsum: pass WF_PRUNED (also to wf_fb_workspace_bytes / wf_fb_backward) exactly when 0 < output_beam < inf");
@@ -3677,30 +3806,36 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     if (rc) return rc;
     for (int i = 0; i < B; ++i)
         if (seg[3 * i + 1] + seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d exceeds Tmax=%d", i, Tmax);
+    Side* side = nullptr;
+    if (use_scratch) {
+        if ((rc = side_get(&side, false))) return rc;
+        return wf_fail(WF_EUNSUPPORTED, "no static scratch in this build");
+    }
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
     std::vector<int32_t> seq2utt;
     if (need_ab || pruned) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
-    rc = upload_tables(P, ws, (need_ab || pruned) ? seq2utt.data() : nullptr, num_seqs, st);
+    rc = upload_tables(P, ws, (need_ab || pruned) ? seq2utt.data() : nullptr, num_seqs, st, !use_scratch);
     if (rc) return rc;
     g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = g_tm.have_check = false;
     // Fork: zero-fill the gradient box on the side stream while the sweeps (which occupy only 2B
     // workgroups) run; post_kernel then only scatters the K posteriors per row.
-    const bool overlap = grad && P.any_compact && !getenv("WF_NO_OVERLAP");
-    Side* side = nullptr;
+    const bool overlap = grad && P.any_compact && !hk().no_overlap;
+    ForkGuard guard(st);   // every return below first makes `st` wait for the side stream
     if ((rc = tm_record(0, st))) return rc;
     rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
     if (rc) return rc;
     if ((rc = tm_record(1, st))) return rc;
     if (overlap) {
         // forked after the gather: both are HBM-bound and would only slow each other down
-        if ((rc = side_get(&side))) return rc;
+        if ((rc = side_get(&side, !use_scratch))) return rc;
         HIP_TRY(hipEventRecord(side->fork, st));
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+        guard.fork(side->stream, side->join);
         if ((rc = tm_record(5, side->stream))) return rc;
         if (strideT == V && strideB == (int64_t)Tmax * V) {
             const size_t n = (size_t)num_seqs * Tmax * V;
-            if (((uintptr_t)grad & 15) == 0 && !getenv("WF_ZERO_MEMSET")) {
+            if (((uintptr_t)grad & 15) == 0 && !hk().zero_memset) {
                 const size_t n4 = n / 4;
                 // Size the grid so that the fill ends about when the sweeps do (~0.15 us per frame step,
                 // ~70 GB/s of streaming stores per workgroup): more workgroups than that only steal
@@ -3708,13 +3843,12 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
                 // (measured on cfg3: 64 blocks -> fill 73 us, sweep 80 us; 256 blocks -> 62 / 98; 1024 -> 74 / 114).
                 int want = (int)((double)n * 4.0 / (std::max(P.Tlong, 1) * 0.15e-6) / 70e9) + 1;
                 want = std::max(32, std::min(want, 2048));
-                if (getenv("WF_ZERO_BLOCKS")) want = atoi(getenv("WF_ZERO_BLOCKS"));
+                if (hk().zero_blocks > 0) want = hk().zero_blocks;
                 const int blocks = (int)std::min<size_t>((n4 + 255) / 256, (size_t)want);
                 // The fill blocks ask for (and never touch) more than half of a CU's LDS: the latency-bound sweep
                 // workgroups do the same, so no fill block lands on a sweep workgroup's CU, where its four waves
                 // would compete with the chain wave for issue slots (measured: the co-resident sweep workgroups
                 // ran 1.6-3.8x longer and set the kernel's duration).
-                constexpr int kFillLds = 84 * 1024;
                 if (!side->fill_attr) {   // once per device (the attribute belongs to the device's copy of the kernel)
                     HIP_TRY(hipFuncSetAttribute((const void*)zero_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFillLds));
                     side->fill_attr = true;
@@ -3732,7 +3866,7 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
         }
         if ((rc = tm_record(6, side->stream))) return rc;
         g_tm.have_zero = g_tm.on;
-        HIP_TRY(hipEventRecord(side->join, side->stream));
+        if ((rc = guard.record())) return rc;
     }
     SweepCfg c = sweep_config(P, ab);
     SweepArgs a{};
@@ -3755,7 +3889,7 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
         if ((rc = tm_record(2, st))) return rc;
         CheckArgs k{a.blob, a.utt, (const double*)a.alpha, (const double*)a.beta, a.aoff, a.boff, a.tot2, a.ctot2,
                     (int32_t*)(ws + P.off_flag), lgrp, llag,
-                    env_int("WF_FORCE_FALLBACK", 0)};
+                    hk().force_fallback};
         hipLaunchKernelGGL(check_kernel, dim3((P.Tlong + 1 + kCheckFR - 1) / kCheckFR, B), dim3(64), 0, st, k);
         HIP_TRY(hipGetLastError());
         SweepCfg fc = sweep_config_minimal(P, ab);
@@ -3802,15 +3936,75 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
     g_tm.have_check = g_tm.on && P.lin;
     if (grad && (flags & WF_PREZERO)) {
         // loss now, gradient later (wf_fb_backward with WF_PREZERO): the fill is done, ordered before whatever follows
-        if (overlap) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
+        if ((rc = guard.wait())) return rc;
     } else if (grad) {
-        if (overlap) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
+        if ((rc = guard.wait())) return rc;
         if ((rc = tm_record(3, st))) return rc;
         rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st);
         if (rc) return rc;
         if ((rc = tm_record(4, st))) return rc;
         g_tm.have_post = g_tm.on;
     }
+    return guard.wait();
+}
+}  // namespace
+
+extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                            const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
+                            int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,
+                            uint32_t flags, const float* grad_scale, float* tot, float* grad,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return fb_logsum_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, Tmax, V, seg, B, output_beam,
+                          flags, grad_scale, tot, grad, workspace, workspace_bytes, stream, false);
+}
+
+// Set-up for the calling host thread on the current device (idempotent): side streams and their events, the pinned
+// staging ring, the device address of the static scratch array.  Other entry points do this lazily on first use;
+// wf_fb_logsum_static requires it to have happened.
+extern "C" int wf_init(void) {
+    Side* s = nullptr;
+    int rc = side_get(&s, true);
+    if (rc) return rc;
+    (void)hk();
+    if (!s->fill_attr) {
+        HIP_TRY(hipFuncSetAttribute((const void*)zero_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFillLds));
+        s->fill_attr = true;
+    }
+    // raise the dynamic-LDS limit of the kernels the allocation-free path may launch, so that it never has to
+    return ensure_band_lds();
+}
+
+// Releases what wf_init / the lazy set-up created for the calling thread (all devices).  Waits for the side streams.
+extern "C" int wf_shutdown(void) {
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    for (int d = 0; d < kMaxDevices; ++d) {
+        Side& s = g_side[d];
+        if (!s.stream) continue;
+        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream2));
+        for (int i = 0; i < kRingSlots; ++i) {
+            if (s.ring_used[i]) HIP_TRY(hipEventSynchronize(s.ring_ev[i]));
+            HIP_TRY(hipEventDestroy(s.ring_ev[i]));
+        }
+        HIP_TRY(hipHostFree(s.ring));
+        HIP_TRY(hipStreamDestroy(s.stream));
+        HIP_TRY(hipStreamDestroy(s.stream2));
+        HIP_TRY(hipEventDestroy(s.fork)); HIP_TRY(hipEventDestroy(s.join));
+        HIP_TRY(hipEventDestroy(s.fork2)); HIP_TRY(hipEventDestroy(s.join2));
+        s = Side();
+    }
+    if (g_tm.made) {
+        for (auto& e : g_tm.ev) HIP_TRY(hipEventDestroy(e));
+        g_tm = Timing();
+    }
+    HIP_TRY(hipSetDevice(cur));
+    return WF_OK;
+}
+
+extern "C" int wf_debug_reload_env(void) {
+    load_hooks();
     return WF_OK;
 }
 
@@ -3885,7 +4079,7 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     if ((rc = tm_record(3, st))) return rc;
     // P.lin repeats the decision the forward call made; the fallback flags are still in the workspace
     // WF_PREZERO: the forward call zero-filled the box under exactly the condition below (its `overlap`)
-    const bool prezeroed = (flags & WF_PREZERO) && P.any_compact && !getenv("WF_NO_OVERLAP");
+    const bool prezeroed = (flags & WF_PREZERO) && P.any_compact && !hk().no_overlap;
     rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, prezeroed, st);
     if (rc) return rc;
     if ((rc = tm_record(4, st))) return rc;
@@ -3968,7 +4162,7 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
                           const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
                           const int32_t* seg, int32_t B, int32_t Tmax, uint32_t flags, float* best_score,
                           int32_t* best_arcs, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!graph_dev || !log_probs || !best_score || !best_arcs || !workspace) return wf_fail(WF_EINVAL, "wf_viterbi: null pointer");
+    if (!graph_dev || !log_probs || !best_score || !best_arcs || !workspace || !seg) return wf_fail(WF_EINVAL, "wf_viterbi: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const bool dbl = flags & WF_DOUBLE_ACC;
     const size_t ab = dbl ? 8 : 4;

@@ -61,7 +61,7 @@ class _FbFunction(torch.autograd.Function):
         gh = graph.blob_host()
         gd = graph.blob_dev(dev)
         n = C.c_size_t(0)
-        _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(gh), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V, flags,
+        _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(gh), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, N, V, flags,
                                               1 if need_grad else 0, C.byref(n)))
         ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
         tot = torch.empty(B, dtype=torch.float32, device=dev)
@@ -171,7 +171,7 @@ def tot_scores(graph: Fsa, dense: DenseFsaVec, log_semiring: bool = True, use_do
     N, T, V = lp.shape
     flags = (_lib.WF_DOUBLE_ACC if use_double_scores else 0) | (0 if log_semiring else _lib.WF_TROPICAL)
     n = C.c_size_t(0)
-    _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V,
+    _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, N, V,
                                           flags, 0, C.byref(n)))
     ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
     tot = torch.empty(B, dtype=torch.float64 if use_double_scores else torch.float32, device=dev)

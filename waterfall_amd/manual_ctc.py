@@ -130,7 +130,7 @@ def compute_align(log_probs: torch.Tensor, input_lengths: torch.Tensor, trans: t
     flags = _lib.WF_KEEP_AB
     gh, gd = graph.blob_host(), graph.blob_dev(dev)
     n = C.c_size_t(0)
-    _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(gh), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V, flags, 1, C.byref(n)))
+    _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(gh), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, N, V, flags, 1, C.byref(n)))
     ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
     tot = torch.empty(B, dtype=torch.float32, device=dev)
     out = torch.empty((B, T, S + 1), dtype=torch.float32, device=dev)   # + the graph's super-final state
