@@ -82,8 +82,8 @@ const char* wf_last_error(void);
 
 /* ---- set-up / tear-down (no counterpart in the reference: k2 owns its CUDA context implicitly) -----
  * wf_init(): set-up for the calling host thread on the CURRENT device (idempotent): side streams + events, the
- * pinned staging ring, kernel attributes.  Optional for every entry
- * point (they do it lazily).  wf_shutdown(): waits for the side streams of the
+ * pinned staging ring, kernel attributes, the device address of the static scratch array.  Optional for every entry
+ * point except wf_fb_logsum_static (the others do it lazily).  wf_shutdown(): waits for the side streams of the
  * calling thread and destroys its contexts on all devices.
  * wf_debug_reload_env(): the WF_* environment test hooks are read once per process; tests that change them call this. */
 int wf_init(void);
@@ -166,6 +166,23 @@ int wf_fb_logsum(const void* graph_host, const void* graph_dev, const int32_t* u
                  int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,
                  uint32_t flags, const float* grad_scale, float* tot, float* grad,
                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the same call for callers that cannot allocate --------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE.  For callers that must not call hipMalloc (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid allocation): wf_fb_logsum with the workspace replaced by a static per-device
+ * array inside the library (WF_STATIC_SCRATCH_BYTES, held by every GPU the library runs on until the process ends).
+ * Same kernels and results as wf_fb_logsum.  Calls nothing that allocates; requires wf_init() by the calling thread on
+ * the current device.  Returns WF_ENOSPC when the call needs more scratch than the array holds (cfg3, B=32 T=500
+ * V=5001 L=64 needs 44 MiB; cfg4's 10 002-state denominators do not fit) or its tables exceed a 64 KiB staging slot,
+ * WF_EUNSUPPORTED for WF_KEEP_AB / WF_PREZERO (a later wf_fb_backward needs a caller workspace) and for graphs beyond
+ * the LDS-resident sweeps.  All calls on one GPU share the array: calls that overlap on one GPU (two streams, two
+ * threads) race; stream-ordered calls are safe.                                                                     */
+#define WF_STATIC_SCRATCH_BYTES (96u << 20)
+int wf_static_scratch_bytes(size_t* bytes);
+int wf_fb_logsum_static(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                        const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
+                        int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,
+                        uint32_t flags, const float* grad_scale, float* tot, float* grad, void* stream);
 
 /* ---- deferred gradient: the autograd backward of graph.py:61-66 --------------------------------
  * Must follow a wf_fb_logsum(..., flags | WF_KEEP_AB, grad = NULL, same graph / seg / workspace) on

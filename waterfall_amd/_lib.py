@@ -52,6 +52,11 @@ _SIGS = {
     "wf_shutdown": (C.c_int, []),
     "wf_debug_reload_env": (C.c_int, []),
     "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),
+    "wf_static_scratch_bytes": (C.c_int, [C.POINTER(_sz)]),
+    "wf_fb_logsum_static": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, C.c_float, _u32,
+                                      _p, _p, _p, _p]),
+    "wf_fb_logsum": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, C.c_float, _u32,
+                               _p, _p, _p, _p, _sz, _p]),
     "wf_fb_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, _u32,
                                  _p, _p, _p, _p, _sz, _p]),
     "wf_state_posteriors": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _u32, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),

@@ -3200,7 +3200,13 @@ int tm_record(int i, hipStream_t st) {
     return WF_OK;
 }
 
+// ---- scratch of the allocation-free entry point (wf_fb_logsum_static): one file-scope device array per GPU.
+// In host code the array's name is only a stand-in; its device address is resolved once per device by wf_init()
+// (hipGetSymbolAddress) and kept in g_scratch_ptr[device] -- host code and kernels only ever see that pointer.
+constexpr size_t kScratchBytes = (size_t)WF_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 16;
+void* g_scratch_ptr[kMaxDevices] = {};
 
 // Per host thread and device: side streams for work that can overlap the latency-bound sweeps, their events, and a
 // ring of pinned staging slots for the per-call tables (so that the host-to-device copy of a call is a true
@@ -3250,6 +3256,12 @@ int side_get(Side** out, bool create = true) {
         for (auto& e : s.ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         int rc = ring_alloc(s, kRingSlotInit);
         if (rc) return rc;
+        if (!g_scratch_ptr[dev]) {
+            void* ptr = nullptr;
+            HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));   // this device's copy of the array
+            g_scratch_ptr[dev] = ptr;
+        }
+        s.scratch_ptr = g_scratch_ptr[dev];
     }
     *out = &s;
     return WF_OK;
@@ -3809,7 +3821,11 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     Side* side = nullptr;
     if (use_scratch) {
         if ((rc = side_get(&side, false))) return rc;
-        return wf_fail(WF_EUNSUPPORTED, "no static scratch in this build");
+        workspace = side->scratch_ptr;
+        workspace_bytes = kScratchBytes;
+        if (P.total + 256 > kScratchBytes)
+            return wf_fail(WF_ENOSPC, "wf_fb_logsum_static: this call needs %zu B of scratch, the static array holds %zu B (use wf_fb_logsum with a caller workspace)", P.total + 256, kScratchBytes);
+        if (P.big) return wf_fail(WF_EUNSUPPORTED, "wf_fb_logsum_static: graphs beyond the LDS-resident sweeps are not supported");
     }
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
@@ -3956,6 +3972,25 @@ extern "C" int wf_fb_logsum(const void* graph_host, const void* graph_dev, const
                             void* workspace, size_t workspace_bytes, void* stream) {
     return fb_logsum_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, Tmax, V, seg, B, output_beam,
                           flags, grad_scale, tot, grad, workspace, workspace_bytes, stream, false);
+}
+
+// The allocation-free variant of wf_fb_logsum: same kernels, same results, the workspace is the library's static
+// per-device scratch array (WF_STATIC_SCRATCH_BYTES).  Calls nothing that allocates: the thread's context (side
+// streams, pinned staging ring, scratch address) must have been set up by wf_init() on the current device.
+extern "C" int wf_fb_logsum_static(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
+                                   const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
+                                   int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,
+                                   uint32_t flags, const float* grad_scale, float* tot, float* grad, void* stream) {
+    if (flags & (WF_KEEP_AB | WF_PREZERO))
+        return wf_fail(WF_EUNSUPPORTED, "wf_fb_logsum_static: WF_KEEP_AB / WF_PREZERO (a later wf_fb_backward) need a caller-owned workspace");
+    return fb_logsum_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, Tmax, V, seg, B, output_beam,
+                          flags, grad_scale, tot, grad, nullptr, 0, stream, true);
+}
+
+extern "C" int wf_static_scratch_bytes(size_t* bytes) {
+    if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
+    *bytes = kScratchBytes;
+    return WF_OK;
 }
 
 // Set-up for the calling host thread on the current device (idempotent): side streams and their events, the pinned
