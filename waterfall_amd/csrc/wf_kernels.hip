@@ -2515,6 +2515,13 @@ struct PostArgs {
     const float* thr;
     const double* aoff;
     const double* boff;
+    // post_small_kernel with the row check folded in (no check_kernel): pass 0 = every utterance's rows are the linear
+    // sweep's; each frame's arc posteriors must sum to 1 (every path takes exactly one arc in frame t), else flag_w[u] is
+    // set and rescue_kernel redoes the utterance afterwards.  pass -1: check_kernel + fallback ran before this launch
+    // (flag tells which rows are which).
+    int pass;
+    int32_t* flag_w;
+    int force;  // test hook (WF_FORCE_FALLBACK): pass 0 flags every utterance
 };
 
 // log2(v) + add for a scaled probability of the linear sweep (0 -> -inf)
@@ -2818,6 +2825,11 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     const double tot = u >= 0 ? p.totd[u] : (double)-INFINITY;
     const int t0 = max(f0 - start, 0), t1 = (u >= 0 && tot != (double)-INFINITY) ? min(f0 + kPostFR - start, T) : 0;
     const int K = (int)U[WF_U_K], direct = (int)U[WF_U_DIRECT];
+    if (p.pass == 0 && u >= 0 && f0 == 0 && lane == 0 && tot == (double)-INFINITY) {
+        // zero total: fine when no path of this length exists, otherwise the linear sweep underflowed
+        const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+        if (T >= I[WF_I_MINLEN]) p.flag_w[u] = 1;
+    }
     if (!p.skip_zero) {
         // rows not pre-zeroed (graphs whose columns are the labels themselves: no side-stream fill): this wave zeroes what
         // it does not write -- whole rows outside the segment / of infeasible utterances, columns K.. of the others
@@ -2834,7 +2846,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     const double* bbase = p.beta + U[WF_U_BETA];
     const float* ebase = direct ? p.lp + (int64_t)q * p.strideB + (int64_t)start * p.strideT : p.E + U[WF_U_E];
     const int64_t epitch = direct ? p.strideT : K;
-    const bool lin = !p.flag[u];   // flagged: the fallback left natural-log fp64 rows
+    const bool lin = p.pass == 0 ? true : !p.flag[u];   // flagged: the fallback left natural-log fp64 rows
     const int32_t* loff = p.blob + U[WF_U_LAB_OFF];
     const int32_t* lsrc = p.blob + U[WF_U_LAB_SRC];
     const int32_t* ldst = p.blob + U[WF_U_LAB_DST];
@@ -2889,6 +2901,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     fetch(t0);
     unsigned long long c_f[kPostFR + 1];
     int nfr = 0;
+    bool bad = p.pass == 0 && p.force;
     for (int t = t0; t < t1; ++t) {
         if (p.prof) c_f[nfr++] = __builtin_amdgcn_s_memtime();
         // ---- this frame's values -> LDS (log2 domain, both vectors centred)
@@ -2922,20 +2935,29 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
         // first drain vmcnt, i.e. wait for the prefetch just issued and for the previous frame's scattered stores
         // (measured: ~4 us of exposed memory latency per frame).  wave_barrier only pins the instruction order.
         __builtin_amdgcn_wave_barrier();
+        float chk = 0.f;
 #pragma unroll
         for (int i = 0; i < PSA; ++i) {
             const int a = lane + i * 64;
-            if (a < A) lpost[a] = __builtin_amdgcn_exp2f(la[asrc[i]] + lb[adst[i]] + (aw[i] + le[acol[i]]));
+            if (a < A) {
+                const float pv = __builtin_amdgcn_exp2f(la[asrc[i]] + lb[adst[i]] + (aw[i] + le[acol[i]]));
+                lpost[a] = pv;
+                chk += pv;
+            }
         }
+        if (p.pass == 0 && !(fabsf(wave_sum(chk) - 1.f) <= kCheckTol)) bad = true;   // wave-uniform
         __builtin_amdgcn_wave_barrier();
         float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)(start + t) * p.strideT;
-        // per-column sums in arc order (bit-stable)
+        // per-column sums in arc order (bit-stable).  The rows were zero-filled: a posterior that is exactly 0 in fp32
+        // (half of them on BASELINE's synthetic cfg3 batch, more for a trained model's peaked posteriors) is not stored --
+        // the kernel is bound by the number of scattered stores (one 128-B line each), not by their bytes.
+        const bool store_zeros = !p.skip_zero;
 #pragma unroll
         for (int i = 0; i < PSS; ++i) {
             if (lane + i * 64 < K && !((heavy[i] >> lane) & 1)) {
                 float acc = 0.f;
                 for (int a = k0[i]; a < k1[i]; ++a) acc += lpost[a];
-                grow[klab[i]] = gs * acc;
+                if (acc != 0.f || store_zeros) grow[klab[i]] = gs * acc;
             }
             unsigned long long hm = heavy[i];
             while (hm) {   // wave-uniform
@@ -2945,15 +2967,140 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
                 float acc = 0.f;
                 for (int a = a0 + lane; a < a1; a += 64) acc += lpost[a];
                 acc = wave_sum(acc);
-                if (lane == hl) grow[klab[i]] = gs * acc;
+                if (lane == hl && (acc != 0.f || store_zeros)) grow[klab[i]] = gs * acc;
             }
         }
         __builtin_amdgcn_wave_barrier();   // la / lb / le / lpost are rewritten by the next frame
     }
+    if (bad && lane == 0) p.flag_w[u] = 1;
     if (p.prof && blockIdx.x == 60 && blockIdx.y == 5 && lane == 0) {
         const unsigned long long c_end = __builtin_amdgcn_s_memtime();
         printf("post_small: setup %llu, frames %llu %llu %llu, last+drain %llu cycles (100 MHz ticks x24)\n", c_f[0] - c_start,
                nfr > 1 ? c_f[1] - c_f[0] : 0ull, nfr > 2 ? c_f[2] - c_f[1] : 0ull, nfr > 3 ? c_f[3] - c_f[2] : 0ull, c_end - c_f[nfr - 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rescue_kernel: the rare path behind post_small_kernel's row check (pass 0).  One workgroup per utterance; exits at
+// once unless flag[u] is set.  For a flagged utterance it redoes everything in the log semiring in fp64 (exp / log
+// in fp64 as well): forward rows, total, backward rows (left in the arenas as natural-log values, the format of the
+// fallback sweep), then the gradient rows -- every label column of every frame is rewritten, zeros included, over
+// whatever pass 0 scattered.  Simple and slow (a state's arcs are summed by one lane), ~1 ms for T = 500: it runs only
+// when the probability-domain sweep lost mass to underflow.  ONE launch instead of a fallback sweep + a second
+// posterior pass: an empty launch costs ~4 us of stream time.
+// ------------------------------------------------------------------------------------------
+struct RescueArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const int32_t* flag;
+    const float* gscale;
+    const float* lp;
+    int64_t strideB, strideT;
+    const float* E;
+    double* alpha;
+    double* beta;
+    float* tot;
+    double* totd;
+    float* grad;
+};
+
+__device__ __forceinline__ double lse2_d(double a, double b) {   // log(exp(a) + exp(b)), -inf safe
+    const double m = fmax(a, b);
+    if (m == (double)-INFINITY) return m;
+    return m + log(exp(a - m) + exp(b - m));
+}
+
+__global__ void __launch_bounds__(256) rescue_kernel(RescueArgs p) {
+    const int u = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (!p.flag[u]) return;
+    __shared__ double s_tot;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int S = I[WF_I_S], K = I[WF_I_K], direct = I[WF_I_DIRECT], T = (int)U[WF_U_T];
+    const int seq = (int)U[WF_U_SEQ], start = (int)U[WF_U_START];
+    const float* ebase = direct ? p.lp + (int64_t)seq * p.strideB + (int64_t)start * p.strideT : p.E + U[WF_U_E];
+    const int64_t epitch = direct ? p.strideT : K;
+    double* A_ = p.alpha + U[WF_U_ALPHA];
+    double* B_ = p.beta + U[WF_U_BETA];
+    // ---- forward
+    {
+        const int32_t* off = p.blob + I[WF_I_IN_OFF];
+        const int32_t* src = p.blob + I[WF_I_IN_SRC];
+        const int32_t* col = p.blob + I[WF_I_IN_COL];
+        const float* w = (const float*)(p.blob + I[WF_I_IN_W]);
+        for (int s = tid; s < S; s += nt) A_[s] = s == 0 ? 0.0 : (double)-INFINITY;
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const double* cur = A_ + (int64_t)t * S;
+            double* nxt = A_ + (int64_t)(t + 1) * S;
+            const float* erow = ebase + (int64_t)t * epitch;
+            for (int s = tid; s < S; s += nt) {
+                double m = (double)-INFINITY;
+                for (int a = off[s]; a < off[s + 1]; ++a) m = fmax(m, cur[src[a]] + (double)(w[a] + erow[col[a]]));
+                double sum = 0.0;
+                if (m > (double)-INFINITY)
+                    for (int a = off[s]; a < off[s + 1]; ++a) sum += exp(cur[src[a]] + (double)(w[a] + erow[col[a]]) - m);
+                nxt[s] = m > (double)-INFINITY ? m + log(sum) : m;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const int NF = I[WF_I_NF];
+            const int32_t* fsrc = p.blob + I[WF_I_FIN_SRC];
+            const float* fw = (const float*)(p.blob + I[WF_I_FIN_W]);
+            const double* last = A_ + (int64_t)T * S;
+            double tot = (double)-INFINITY;
+            for (int i = 0; i < NF; ++i) tot = lse2_d(tot, last[fsrc[i]] + (double)fw[i]);
+            s_tot = tot;
+            p.tot[u] = (float)tot;
+            p.totd[u] = tot;
+        }
+    }
+    // ---- backward
+    {
+        const int32_t* off = p.blob + I[WF_I_OUT_OFF];
+        const int32_t* dst = p.blob + I[WF_I_OUT_DST];
+        const int32_t* col = p.blob + I[WF_I_OUT_COL];
+        const float* w = (const float*)(p.blob + I[WF_I_OUT_W]);
+        const float* fb = (const float*)(p.blob + I[WF_I_FINB_LOG]);
+        for (int s = tid; s < S; s += nt) B_[(int64_t)T * S + s] = (double)fb[s];
+        __syncthreads();
+        for (int t = T - 1; t >= 0; --t) {
+            const double* nxt = B_ + (int64_t)(t + 1) * S;
+            double* cur = B_ + (int64_t)t * S;
+            const float* erow = ebase + (int64_t)t * epitch;
+            for (int s = tid; s < S; s += nt) {
+                double m = (double)-INFINITY;
+                for (int a = off[s]; a < off[s + 1]; ++a) m = fmax(m, nxt[dst[a]] + (double)(w[a] + erow[col[a]]));
+                double sum = 0.0;
+                if (m > (double)-INFINITY)
+                    for (int a = off[s]; a < off[s + 1]; ++a) sum += exp(nxt[dst[a]] + (double)(w[a] + erow[col[a]]) - m);
+                cur[s] = m > (double)-INFINITY ? m + log(sum) : m;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- gradient rows: per label column, its arcs in column-sorted (= arc) order
+    if (!p.grad) return;
+    const double tot = s_tot;
+    const int32_t* loff = p.blob + I[WF_I_LAB_OFF];
+    const int32_t* lsrc = p.blob + I[WF_I_LAB_SRC];
+    const int32_t* ldst = p.blob + I[WF_I_LAB_DST];
+    const float* lw = (const float*)(p.blob + I[WF_I_LAB_W]);
+    const int32_t* labels = p.blob + I[WF_I_LABELS];
+    const float gs = p.gscale ? p.gscale[u] : 1.f;
+    for (int64_t j = tid; j < (int64_t)T * K; j += nt) {
+        const int t = (int)(j / K), k = (int)(j - (int64_t)t * K);
+        float val = 0.f;
+        if (tot > (double)-INFINITY) {
+            const double* ar = A_ + (int64_t)t * S;
+            const double* br = B_ + (int64_t)(t + 1) * S;
+            const double e = (double)ebase[(int64_t)t * epitch + k];
+            double acc = 0.0;
+            for (int a = loff[k]; a < loff[k + 1]; ++a) acc += exp(ar[lsrc[a]] + ((double)lw[a] + e) + br[ldst[a]] - tot);
+            val = gs * (float)acc;
+        }
+        p.grad[(int64_t)seq * p.strideB + (int64_t)(start + t) * p.strideT + (direct ? k : labels[k])] = val;
     }
 }
 
@@ -3043,7 +3190,7 @@ constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where not
 struct Hooks {
     int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
         zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache,
-        post_profile, sweep_profile, quad_r, no_fused_gather, no_post_check;
+        post_profile, sweep_profile, quad_r, no_post_check;
 };
 Hooks g_hooks;
 bool g_hooks_loaded = false;
@@ -3064,7 +3211,7 @@ void load_hooks() {
     h.sweep_ablate = env_int("WF_SWEEP_ABLATE", 0); h.no_arc_cache = env_int("WF_NO_ARC_CACHE", 0);
     h.post_profile = env_int("WF_POST_PROFILE", 0); h.sweep_profile = env_int("WF_SWEEP_PROFILE", 0);
     h.quad_r = env_int("WF_QUAD_R", 0);
-    h.no_fused_gather = env_int("WF_NO_FUSED_GATHER", 0); h.no_post_check = env_int("WF_NO_POST_CHECK", 0);
+    h.no_post_check = env_int("WF_NO_POST_CHECK", 0);
     g_hooks = h;
     g_hooks_loaded = true;
 }
@@ -3075,6 +3222,7 @@ inline const Hooks& hk() {
 struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; bool gen = false; };
 BandSel band_config(const Plan& P);
 bool linbig_config(const Plan& P);
+bool post_small_fits(const Plan& P);
 
 // dbl_exact: WF_DOUBLE_ACC (k2 use_double_scores=True): exp/log in fp64 too, log-semiring sweep only
 int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V,
@@ -3133,6 +3281,15 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         if (!I[WF_I_BAND_WE]) P->band_we = false;
         row0 += T;
     }
+    // graphs whose sweep state does not fit the LDS (or, test hook, with at least WF_BIG_MIN_S states): per-frame launches
+    P->big = sweep_lds_bytes(*P, acc_bytes) > kLdsBudget || P->smax >= hk().big_min_s;
+    if (mode == 0) {
+        if (P->big && pruned)
+            return wf_fail(WF_EUNSUPPORTED, "output_beam pruning is not available for graphs beyond the LDS-resident sweeps (%d states)", P->smax);
+        P->pruned = pruned;
+        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok || linbig_config(*P));
+        P->linbig = P->lin && !band_config(*P).ok && !lin_config(*P).ok;
+    }
     P->n_E = nE; P->n_ab = nab; P->n_P = nP; P->n_rows = row0;
     size_t o = 0;
     P->off_utt = o; o = align_up(o + sizeof(int64_t) * WF_U_WORDS * B, 256);
@@ -3142,16 +3299,9 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     P->off_totd = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_tot2 = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
-    // graphs whose sweep state does not fit the LDS (or, test hook, with at least WF_BIG_MIN_S states): per-frame launches
-    P->big = sweep_lds_bytes(*P, acc_bytes) > kLdsBudget || P->smax >= hk().big_min_s;
     if (mode == 0) {
-        if (P->big && pruned)
-            return wf_fail(WF_EUNSUPPORTED, "output_beam pruning is not available for graphs beyond the LDS-resident sweeps (%d states)", P->smax);
-        P->pruned = pruned;
-        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok || linbig_config(*P));
         P->off_ctot2 = o; o = align_up(o + sizeof(double) * B, 256);
         P->off_flag = o; o = align_up(o + sizeof(int32_t) * B, 256);
-        P->linbig = P->lin && !band_config(*P).ok && !lin_config(*P).ok;
         if (P->lin) {
             P->off_P = o; o = align_up(o + (P->linbig ? sizeof(float) * ((size_t)nP + kLBSlot * kMaxThreads) : sizeof(double) * (size_t)nP), 256);
             P->off_cmax = o; o = align_up(o + sizeof(double) * (size_t)std::max<int64_t>(row0, 1), 256);
@@ -3188,6 +3338,7 @@ struct Timing {
     hipEvent_t ev[8] = {};   // t0 | gather | sweep | (post t0) | post | zero t0 | zero t1 | check + fallback
     bool made = false;
     bool have_fwd = false, have_post = false, have_zero = false, have_check = false;
+    int check_from = 2;   // event that opens the "check + fallback" interval (2: after the sweep; 4: after the posterior kernel)
 };
 thread_local Timing g_tm;
 int tm_record(int i, hipStream_t st) {
@@ -3728,10 +3879,49 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
     return WF_OK;
 }
 
+// post_small_kernel's size limits (one wavefront per 4 frames, <= 8 arc / 8 state / 8 column slots per lane)
+bool post_small_fits(const Plan& P) {
+    return !hk().no_post_small && P.amax >= 1 && P.amax <= 128 * 8 && P.smax <= 64 * 8 && P.kmax <= 64 * 8;
+}
+
+// zero-fill of the B x Tmax x V gradient box on `st`; blocks_hint: workgroups of the flat kernel (0: as many as it takes)
+int launch_zero(float* grad, int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, int blocks_hint, Side* side,
+                hipStream_t st) {
+    if (strideT == V && strideB == (int64_t)Tmax * V) {
+        const size_t n = (size_t)num_seqs * Tmax * V;
+        if (((uintptr_t)grad & 15) == 0 && !hk().zero_memset) {
+            const size_t n4 = n / 4;
+            int want = blocks_hint > 0 ? blocks_hint : 2048;
+            if (hk().zero_blocks > 0) want = hk().zero_blocks;
+            const int blocks = (int)std::min<size_t>((n4 + 255) / 256, (size_t)want);
+            // The fill blocks ask for (and never touch) more than half of a CU's LDS: the latency-bound sweep
+            // workgroups do the same, so no fill block lands on a sweep workgroup's CU, where its four waves
+            // would compete with the chain wave for issue slots (measured: the co-resident sweep workgroups
+            // ran 1.6-3.8x longer and set the kernel's duration).
+            if (!side->fill_attr) {   // once per device (the attribute belongs to the device's copy of the kernel)
+                HIP_TRY(hipFuncSetAttribute((const void*)zero_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFillLds));
+                side->fill_attr = true;
+            }
+            hipLaunchKernelGGL(zero_flat_kernel, dim3(std::max(blocks, 1)), dim3(256), kFillLds, st,
+                               (float4*)grad, n4, grad + n4 * 4, (int)(n - n4 * 4));
+            HIP_TRY(hipGetLastError());
+        } else {
+            HIP_TRY(hipMemsetAsync(grad, 0, sizeof(float) * n, st));
+        }
+    } else {
+        ZeroArgs z{grad, strideB, strideT, V};
+        hipLaunchKernelGGL(zero_kernel, dim3(Tmax, num_seqs), dim3(256), 0, st, z);
+        HIP_TRY(hipGetLastError());
+    }
+    return WF_OK;
+}
+
+// pass: PostArgs::pass (-1: check_kernel ran before; 0: post_small_kernel checks the rows itself)
 int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                 int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
-                float* grad, bool skip_zero, hipStream_t st) {
+                float* grad, bool skip_zero, hipStream_t st, int pass = -1) {
     PostArgs q{};
+    q.pass = pass; q.flag_w = (int32_t*)(ws + P.off_flag); q.force = hk().force_fallback;
     {
         int grp = 0, lag = 0;
         lin_grp_lag(P, &grp, &lag);
@@ -3756,8 +3946,7 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     size_t lds = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
     // pre-zeroed rows (some graph compact: the side-stream fill covered the whole box), or only graphs whose columns are the
     // labels (the kernel zeroes the few columns it does not write)
-    if (P.lin && (skip_zero || !P.any_compact) && !hk().no_post_small && P.amax >= 1 && P.amax <= 128 * 8 && P.smax <= 64 * 8 &&
-        P.kmax <= 64 * 8) {
+    if (P.lin && (skip_zero || !P.any_compact) && post_small_fits(P)) {
         q.ecap = (int)align_up(P.kmax, 4);
         q.acap = (int)align_up(P.amax, 4);
         size_t lds2 = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
@@ -3837,6 +4026,9 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     // Fork: zero-fill the gradient box on the side stream while the sweeps (which occupy only 2B
     // workgroups) run; post_kernel then only scatters the K posteriors per row.
     const bool overlap = grad && P.any_compact && !hk().no_overlap;
+    // the row check folded into post_small_kernel (no check_kernel launch): when the gradient is computed by this call
+    const bool postcheck = P.lin && grad && !(flags & WF_PREZERO) && (overlap || !P.any_compact) && post_small_fits(P) &&
+                           !hk().no_post_check;
     ForkGuard guard(st);   // every return below first makes `st` wait for the side stream
     if ((rc = tm_record(0, st))) return rc;
     rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
@@ -3849,37 +4041,13 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
         HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
         guard.fork(side->stream, side->join);
         if ((rc = tm_record(5, side->stream))) return rc;
-        if (strideT == V && strideB == (int64_t)Tmax * V) {
-            const size_t n = (size_t)num_seqs * Tmax * V;
-            if (((uintptr_t)grad & 15) == 0 && !hk().zero_memset) {
-                const size_t n4 = n / 4;
-                // Size the grid so that the fill ends about when the sweeps do (~0.15 us per frame step,
-                // ~70 GB/s of streaming stores per workgroup): more workgroups than that only steal
-                // issue slots and memory-queue space from the latency-bound sweep workgroups
-                // (measured on cfg3: 64 blocks -> fill 73 us, sweep 80 us; 256 blocks -> 62 / 98; 1024 -> 74 / 114).
-                int want = (int)((double)n * 4.0 / (std::max(P.Tlong, 1) * 0.15e-6) / 70e9) + 1;
-                want = std::max(32, std::min(want, 2048));
-                if (hk().zero_blocks > 0) want = hk().zero_blocks;
-                const int blocks = (int)std::min<size_t>((n4 + 255) / 256, (size_t)want);
-                // The fill blocks ask for (and never touch) more than half of a CU's LDS: the latency-bound sweep
-                // workgroups do the same, so no fill block lands on a sweep workgroup's CU, where its four waves
-                // would compete with the chain wave for issue slots (measured: the co-resident sweep workgroups
-                // ran 1.6-3.8x longer and set the kernel's duration).
-                if (!side->fill_attr) {   // once per device (the attribute belongs to the device's copy of the kernel)
-                    HIP_TRY(hipFuncSetAttribute((const void*)zero_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFillLds));
-                    side->fill_attr = true;
-                }
-                hipLaunchKernelGGL(zero_flat_kernel, dim3(std::max(blocks, 1)), dim3(256), kFillLds, side->stream,
-                                   (float4*)grad, n4, grad + n4 * 4, (int)(n - n4 * 4));
-                HIP_TRY(hipGetLastError());
-            } else {
-                HIP_TRY(hipMemsetAsync(grad, 0, sizeof(float) * n, side->stream));
-            }
-        } else {
-            ZeroArgs z{grad, strideB, strideT, V};
-            hipLaunchKernelGGL(zero_kernel, dim3(Tmax, num_seqs), dim3(256), 0, side->stream, z);
-            HIP_TRY(hipGetLastError());
-        }
+        // Size the grid so that the fill ends about when the sweeps do (~0.15 us per frame step,
+        // ~70 GB/s of streaming stores per workgroup): more workgroups than that only steal
+        // issue slots and memory-queue space from the latency-bound sweep workgroups
+        // (measured on cfg3: 64 blocks -> fill 73 us, sweep 80 us; 256 blocks -> 62 / 98; 1024 -> 74 / 114).
+        int want = (int)((double)num_seqs * Tmax * V * 4.0 / (std::max(P.Tlong, 1) * 0.15e-6) / 70e9) + 1;
+        want = std::max(32, std::min(want, 2048));
+        if ((rc = launch_zero(grad, strideB, strideT, num_seqs, Tmax, V, want, side, side->stream))) return rc;
         if ((rc = tm_record(6, side->stream))) return rc;
         g_tm.have_zero = g_tm.on;
         if ((rc = guard.record())) return rc;
@@ -3903,18 +4071,38 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
         rc = bs.ok ? launch_sweep_band(bs, a, B, st) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
+        SweepCfg fc = sweep_config_minimal(P, ab);
+        SweepArgs fa = a;
+        fa.flag = (const int32_t*)(ws + P.off_flag);
+        fa.chunk = fc.chunk; fa.kpad = fc.kpad; fa.smax = fc.smax; fa.arcs_lds_words = 0; fa.hcap = fc.hcap;
+        if (postcheck) {
+            // posterior rows first (pass 0 checks every frame and flags what fails), then ONE launch that redoes the
+            // flagged utterances in the log semiring (exits at once when nothing is flagged)
+            if ((rc = guard.wait())) return rc;
+            if ((rc = tm_record(3, st))) return rc;
+            rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st, 0);
+            if (rc) return rc;
+            if ((rc = tm_record(4, st))) return rc;
+            g_tm.have_post = g_tm.on;
+            RescueArgs r{a.blob, a.utt, (const int32_t*)(ws + P.off_flag), grad_scale, log_probs, strideB, strideT, a.E,
+                         (double*)a.alpha, (double*)a.beta, tot, a.totd, grad};
+            hipLaunchKernelGGL(rescue_kernel, dim3(B), dim3(256), 0, st, r);
+            HIP_TRY(hipGetLastError());
+            if ((rc = tm_record(7, st))) return rc;
+            g_tm.have_fwd = g_tm.on;
+            g_tm.have_check = g_tm.on;
+            g_tm.check_from = 4;
+            return guard.wait();
+        }
         CheckArgs k{a.blob, a.utt, (const double*)a.alpha, (const double*)a.beta, a.aoff, a.boff, a.tot2, a.ctot2,
                     (int32_t*)(ws + P.off_flag), lgrp, llag,
                     hk().force_fallback};
         hipLaunchKernelGGL(check_kernel, dim3((P.Tlong + 1 + kCheckFR - 1) / kCheckFR, B), dim3(64), 0, st, k);
         HIP_TRY(hipGetLastError());
-        SweepCfg fc = sweep_config_minimal(P, ab);
-        SweepArgs fa = a;
-        fa.flag = (const int32_t*)(ws + P.off_flag);
-        fa.chunk = fc.chunk; fa.kpad = fc.kpad; fa.smax = fc.smax; fa.arcs_lds_words = 0; fa.hcap = fc.hcap;
         rc = launch_sweep<double, float, M_FB>(fc, fa, B, st);
         if (rc) return rc;
         if ((rc = tm_record(7, st))) return rc;
+        g_tm.check_from = 2;
     } else if (pruned) {
         // pass 1: tropical forward-backward (fp32, every row kept); pass 2: log semiring over the kept arcs
         SweepCfg tc = sweep_config(P, 4);
@@ -4079,7 +4267,7 @@ extern "C" int wf_timing_read(float* ms) {
     ms[0] = ms[1] = ms[2] = ms[3] = ms[4] = -1.f;
     if (g_tm.have_check) {
         HIP_TRY(hipEventSynchronize(g_tm.ev[7]));
-        HIP_TRY(hipEventElapsedTime(&ms[4], g_tm.ev[2], g_tm.ev[7]));
+        HIP_TRY(hipEventElapsedTime(&ms[4], g_tm.ev[g_tm.check_from], g_tm.ev[7]));
     }
     if (g_tm.have_fwd) {
         HIP_TRY(hipEventSynchronize(g_tm.ev[2]));
