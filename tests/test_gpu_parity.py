@@ -298,6 +298,7 @@ def test_full_size_mmictc_denominator_properties(oracle_lib):
 SWEEP_PATHS = {
     "default": {},                                                        # banded sweep, row check inside post_small_kernel
     "check_kernel": {"WF_NO_POST_CHECK": "1"},                             # separate row-check kernel before the posterior kernel
+    "fill_side_stream": {"WF_FILL_SIDE_STREAM": "1"},                      # gradient zero-fill on the side stream instead of inside the sweep's launch
     "band_then_fallback_check_kernel": {"WF_FORCE_FALLBACK": "1", "WF_NO_POST_CHECK": "1"},
     "no_gen_wave": {"WF_NO_GEN_SWEEP": "1"},                              # cyclic graphs <= 64 states: sweep_lin instead of the wave kernel's general mode
     "lin_lds": {"WF_NO_BAND_SWEEP": "1"},                                 # <= 64 states: the wave-resident variant (ds_bpermute)

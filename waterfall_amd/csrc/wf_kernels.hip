@@ -123,6 +123,14 @@ struct SweepArgs {
     int arcs_lds_words;  // words reserved for the LDS copy of the CSR arrays
     int hcap;      // heavy states reduced per cooperative round (sizes the LDS reduction scratch)
     int tot_double;
+    // sweep_band_kernel: workgroups >= nsweep of the launch zero-fill the gradient box (n4 float4 + a tail) instead of
+    // sweeping -- the fill that otherwise runs beside the sweep on a side stream, without the fork / join events
+    // (two dependent queue packets each).  nsweep == gridDim.x: no fill attached.
+    float4* zp;
+    size_t zn4;
+    float* ztail;
+    int zntail;
+    int nsweep;
     int ablate;    // measurement aids, never set by the product path: bit 8 (WF_SWEEP_PROFILE=1) workgroup 0 prints its cycles per
                    // frame step; sweep_kernel, WF_SWEEP_ABLATE: 16 no register copy of streamed arcs, 32 no row stores, 64 no heavy
                    // states, 128 no light states (32-128 give wrong results: timing only)
@@ -1538,6 +1546,17 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
     int* ebuf = (int*)(smem + 2 * kBandPBytes);
     int* shw = ebuf + 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= p.nsweep) {
+        // fill role: these workgroups are dispatched after the 2B sweep workgroups and, like them, own their CU (the
+        // kernel's LDS request), so no fill wave competes with a chain wave for issue slots
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f z = {0.f, 0.f, 0.f, 0.f};
+        const size_t stride = (size_t)(gridDim.x - p.nsweep) * 128;
+        for (size_t i = (size_t)(blockIdx.x - p.nsweep) * 128 + tid; i < p.zn4; i += stride)
+            __builtin_nontemporal_store(z, (v4f*)p.zp + i);
+        if ((int)blockIdx.x == p.nsweep && tid < p.zntail) p.ztail[tid] = 0.f;
+        return;
+    }
     const int u = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int fsa = uni((int)U[WF_U_FSA]), T = uni((int)U[WF_U_T]);
@@ -3190,7 +3209,7 @@ constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where not
 struct Hooks {
     int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
         zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache,
-        post_profile, sweep_profile, quad_r, no_post_check;
+        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream;
 };
 Hooks g_hooks;
 bool g_hooks_loaded = false;
@@ -3211,7 +3230,7 @@ void load_hooks() {
     h.sweep_ablate = env_int("WF_SWEEP_ABLATE", 0); h.no_arc_cache = env_int("WF_NO_ARC_CACHE", 0);
     h.post_profile = env_int("WF_POST_PROFILE", 0); h.sweep_profile = env_int("WF_SWEEP_PROFILE", 0);
     h.quad_r = env_int("WF_QUAD_R", 0);
-    h.no_post_check = env_int("WF_NO_POST_CHECK", 0);
+    h.no_post_check = env_int("WF_NO_POST_CHECK", 0); h.fill_side_stream = env_int("WF_FILL_SIDE_STREAM", 0);
     g_hooks = h;
     g_hooks_loaded = true;
 }
@@ -3692,22 +3711,24 @@ BandSel band_config(const Plan& P) {
 }
 
 template <int R, int BW, int MM, bool WE, bool GEN = false>
-int launch_band_one(const SweepArgs& a, int B, hipStream_t st) {
+int launch_band_one(SweepArgs a, int B, hipStream_t st, int nfill) {
     auto k = sweep_band_kernel<R, BW, MM, WE, GEN>;
     { int rc_ = ensure_lds((const void*)k, kBandLds); if (rc_) return rc_; }
-    hipLaunchKernelGGL(k, dim3(B * 2), dim3(128), kBandLds, st, a);
+    a.nsweep = B * 2;
+    hipLaunchKernelGGL(k, dim3(B * 2 + nfill), dim3(128), kBandLds, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
 
-int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st) {
+// nfill > 0: that many extra workgroups zero-fill a.zp / a.ztail (see SweepArgs)
+int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st, int nfill = 0) {
     const int prof = hk().sweep_profile;
     a.ablate = prof;
-    if (b.gen) return b.we ? launch_band_one<1, 1, 1, true, true>(a, B, st) : launch_band_one<1, 1, 1, false, true>(a, B, st);
+    if (b.gen) return b.we ? launch_band_one<1, 1, 1, true, true>(a, B, st, nfill) : launch_band_one<1, 1, 1, false, true>(a, B, st, nfill);
 #define WF_BAND_CASE(RR, WW)                                                                     \
     if (b.BW == WW && b.R == RR)                                                                  \
-        return b.we ? launch_band_one<RR, WW, 1, true>(a, B, st)                                   \
-                    : (b.M == 1 ? launch_band_one<RR, WW, 1, false>(a, B, st) : launch_band_one<RR, WW, 2, false>(a, B, st))
+        return b.we ? launch_band_one<RR, WW, 1, true>(a, B, st, nfill)                                   \
+                    : (b.M == 1 ? launch_band_one<RR, WW, 1, false>(a, B, st, nfill) : launch_band_one<RR, WW, 2, false>(a, B, st, nfill))
     WF_BAND_CASE(2, 2);
     WF_BAND_CASE(3, 2);
     WF_BAND_CASE(4, 2);
@@ -4034,7 +4055,22 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
     if (rc) return rc;
     if ((rc = tm_record(1, st))) return rc;
-    if (overlap) {
+    // The fill rides in the banded sweep's own launch (extra workgroups) when the box is one flat, 16-byte aligned run and
+    // sweep + fill workgroups all fit the chip at one per CU; otherwise it goes to the side stream.
+    int fill_want = (int)((double)num_seqs * Tmax * V * 4.0 / (std::max(P.Tlong, 1) * 0.15e-6) / 70e9) + 1;
+    fill_want = std::max(32, std::min(fill_want, 2048));
+    if (hk().zero_blocks > 0) fill_want = hk().zero_blocks;
+    const bool flat = strideT == V && strideB == (int64_t)Tmax * V && ((uintptr_t)grad & 15) == 0;
+    // 128-lane fill workgroups in the sweep's launch: ~80 GB/s each, sized to end with the sweep (~0.095 us per frame step).
+    // More of them slow the chain waves down (measured on cfg3, ms per step: 32 -> 0.177, 44 -> 0.144, 68 -> 0.112,
+    // 80 -> 0.1037, 100 -> 0.1044, 124 -> 0.110, 180 -> 0.119)
+    int nfill_sweep = (int)((double)num_seqs * Tmax * V * 4.0 / (std::max(P.Tlong, 1) * 0.095e-6) / 80e9) + 1;
+    nfill_sweep = std::max(16, nfill_sweep);
+    if (hk().zero_blocks > 0) nfill_sweep = 2 * hk().zero_blocks;
+    const bool fill_in_sweep = overlap && P.lin && band_config(P).ok && flat && !hk().fill_side_stream && !hk().zero_memset &&
+                               2 * B + nfill_sweep <= 256;
+    if (fill_in_sweep) g_tm.have_zero = false;
+    if (overlap && !fill_in_sweep) {
         // forked after the gather: both are HBM-bound and would only slow each other down
         if ((rc = side_get(&side, !use_scratch))) return rc;
         HIP_TRY(hipEventRecord(side->fork, st));
@@ -4045,9 +4081,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
         // ~70 GB/s of streaming stores per workgroup): more workgroups than that only steal
         // issue slots and memory-queue space from the latency-bound sweep workgroups
         // (measured on cfg3: 64 blocks -> fill 73 us, sweep 80 us; 256 blocks -> 62 / 98; 1024 -> 74 / 114).
-        int want = (int)((double)num_seqs * Tmax * V * 4.0 / (std::max(P.Tlong, 1) * 0.15e-6) / 70e9) + 1;
-        want = std::max(32, std::min(want, 2048));
-        if ((rc = launch_zero(grad, strideB, strideT, num_seqs, Tmax, V, want, side, side->stream))) return rc;
+        if ((rc = launch_zero(grad, strideB, strideT, num_seqs, Tmax, V, fill_want, side, side->stream))) return rc;
         if ((rc = tm_record(6, side->stream))) return rc;
         g_tm.have_zero = g_tm.on;
         if ((rc = guard.record())) return rc;
@@ -4068,7 +4102,13 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
         const BandSel bs = band_config(P);
         int lgrp = 0, llag = 0;
         lin_grp_lag(P, &lgrp, &llag);
-        rc = bs.ok ? launch_sweep_band(bs, a, B, st) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
+        int nfill = 0;
+        if (fill_in_sweep) {
+            const size_t n = (size_t)num_seqs * Tmax * V;
+            a.zp = (float4*)grad; a.zn4 = n / 4; a.ztail = grad + (n / 4) * 4; a.zntail = (int)(n - (n / 4) * 4);
+            nfill = nfill_sweep;
+        }
+        rc = bs.ok ? launch_sweep_band(bs, a, B, st, nfill) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
         SweepCfg fc = sweep_config_minimal(P, ab);
