@@ -275,6 +275,87 @@ def cpu_baseline(wl, budget_s=12.0):
     return out
 
 
+def _wall_and_host(fn, steps, warmup=3):
+    """(wall ms per step, host-issue ms per step): the loop is timed until it has issued everything (host) and until
+    the GPU has finished it (wall)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    return (t2 - t0) / steps * 1e3, (t1 - t0) / steps * 1e3
+
+
+def dropin_times(wl, steps):
+    """What a caller of the reference gets per step: k2.DenseFsaVec(...) -> graphloss(reduction='sum') -> backward()
+    (models.py:256-277), on the resident graph and with fresh numerator graphs every step (linear_fsa ->
+    remove_epsilon_and_add_self_loops -> arc_sort -> compose, models.py:263-270, + upload), next to the fused C call."""
+    w = WORKLOADS[wl.name]
+    segs_t = torch.from_numpy(wl.segs)
+    x = wl.lp.detach().requires_grad_(True)
+
+    def dropin(fsa=None):
+        x.grad = None
+        dense = wf.DenseFsaVec(x, segs_t)
+        loss = wf.graphloss(fsa if fsa is not None else wl.fsa, dense, output_beam=10, reduction="sum")
+        loss.backward()
+
+    out = {}
+    wall, host = _wall_and_host(dropin, steps)
+    out["dropin"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
+                     "what": "DenseFsaVec + graphloss(reduction='sum') + backward() under autograd, resident graph"}
+    if w["den"]:
+        return out
+    # fresh transcripts every step: `steps + 3` different batches drawn beforehand (flat int32 labels + lengths, as a data
+    # loader holds them)
+    rng = np.random.default_rng(4242)
+    P, L, B = w["P"], w["L"], wl.B
+    phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
+    topo = wf.Topology(w["topo"], phones)
+    batches = [(rng.integers(2, P + 2, size=B * L).astype(np.int32), np.full(B, L)) for _ in range(steps + 3)]
+    it = [0]
+
+    def compile_only():
+        b = batches[it[0] % len(batches)]
+        it[0] += 1
+        return wf.compile_ctc_k2_graphs(topo, b)
+
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        compile_only()
+    out["compile_host_ms"] = (time.perf_counter() - t0) / steps * 1e3
+
+    def fresh_dropin():
+        dropin(compile_only())
+
+    lib = _lib.lib()
+    stream = torch.cuda.current_stream(wl.dev).cuda_stream
+
+    def fresh_fused():
+        fsa = compile_only()
+        gh, gd = fsa.blob_host(), fsa.blob_dev(wl.dev)
+        lp = wl.lp
+        n = C.c_size_t(0)     # the workspace depends on the batch's graphs (distinct labels per utterance)
+        _lib.check(lib.wf_fb_workspace_bytes(_np(gh), None, _np(wl.segs), wl.B, wl.B, wl.V, 0, 1, C.byref(n)))
+        ws = torch.empty(n.value, dtype=torch.uint8, device=wl.dev)
+        _lib.check(lib.wf_fb_logsum(_np(gh), _ptr(gd), None, _ptr(lp), lp.stride(0), lp.stride(1), wl.B, wl.T, wl.V,
+                                    _np(wl.segs), wl.B, 0.0, 0, _ptr(wl.gscale), _ptr(wl.tot), _ptr(wl.grad), _ptr(ws),
+                                    n.value, C.c_void_p(stream)))
+
+    wall, host = _wall_and_host(fresh_dropin, steps)
+    out["fresh_graphs_dropin"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
+                                  "what": "new transcripts every step: compile_ctc_k2_graphs (compose + prepare, "
+                                          f"{wf.compile.host_threads()} host threads) + asynchronous upload + the drop-in loss + backward"}
+    wall, host = _wall_and_host(fresh_fused, steps)
+    out["fresh_graphs"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
+                           "what": "new transcripts every step: compile + asynchronous upload + the fused wf_fb_logsum call"}
+    return out
+
+
 def viterbi_bench(dev, S, B=8, T=500, V=5001, reps=3):
     """cfg5: tropical best path + back-trace on a synthetic TLG-like graph (A = 3 S) shared by
     the batch; exact search.  Algorithmic bytes per utterance-frame: 4 V + 16 A + 4 S."""
@@ -387,6 +468,11 @@ def main():
                               "GBps": kb[k] / (kt[k] * 1e-3) / 1e9 if kt[k] > 0 else None} for k in kt}
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
         out["path_GBps_survey_8d"] = kb["path_survey_8d"] / (ms_step * 1e-3) / 1e9
+        if world == 1:
+            try:
+                out.update(dropin_times(wl, max(20, args.steps)))
+            except Exception as e:   # noqa: BLE001
+                out["dropin"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wl)

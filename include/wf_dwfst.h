@@ -118,7 +118,8 @@ int wf_compose_linear(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t
  * ctc_cross != 0: topo is the CTC topology (utils/get_token_fst_ctc.py:25-53) WITHOUT its O(P^2) arcs
  * "state of another phone -> state of phone p, p : p" (:37-40), which are then implied by phone_state[p] /
  * phone_token[p] (int32[num_phones], 0 = the phone has no state): 25 M arcs at P = 5000 are never built.   */
-int wf_topo_index_words(int32_t topo_num_arcs, int32_t topo_num_states, int64_t* words);
+int wf_topo_index_words(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs, int32_t topo_num_states,
+                        int64_t* words);
 int wf_topo_index_build(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs,
                         int32_t topo_num_states, int32_t* index);
 int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs,
@@ -127,6 +128,20 @@ int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* topo_aux, i
                             const int32_t* phones, const int32_t* phones_off, int32_t B,
                             int32_t* out_arcs, int32_t* out_aux, int64_t arc_capacity,
                             int32_t* out_arc_off, int32_t* out_num_states);
+
+/* wf_compose_linear_batch + wf_graph_prepare in ONE call, the utterances spread over `nthreads` persistent host threads:
+ * what a training step needs between the data loader and the loss (models.py:263-270 / datapipe.py:233-256 run on every
+ * step).  Writes the FsaVec arrays as wf_compose_linear_batch does and the prepared blob (give it pinned memory and
+ * upload with one asynchronous copy).  Every graph sits at the start of an upper-bound region of the blob (gaps in
+ * between), so the words to upload are blob[2] (WF_H_WORDS).  WF_ENOSPC: out_arc_off[B] arcs / *blob_bytes_needed
+ * bytes are needed.                                                                                                 */
+int wf_numerator_compile(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs,
+                         int32_t topo_num_states, const int32_t* index, int32_t ctc_cross,
+                         const int32_t* phone_state, const int32_t* phone_token, int32_t num_phones,
+                         const int32_t* phones, const int32_t* phones_off, int32_t B,
+                         int32_t* out_arcs, int32_t* out_aux, int64_t arc_capacity,
+                         int32_t* out_arc_off, int32_t* out_num_states,
+                         void* blob, size_t blob_bytes, size_t* blob_bytes_needed, int32_t nthreads);
 
 /* The same for ARBITRARY epsilon-free right-hand graphs (one per utterance), e.g. the phone-level graph of a word
  * sequence under a lexicon with alternative pronunciations and optional silence (datapipe.py:244-254: L_inv o words,
@@ -193,6 +208,18 @@ int wf_fb_backward(const void* graph_host, const void* graph_dev, const int32_t*
                    int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, uint32_t flags,
                    const float* grad_scale, const float* tot, float* grad,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the drop-in's eager gradient (graph.py:66-76 + autograd; waterfall_amd/graph.py) ----------------------------
+ * graphloss() under autograd runs the FUSED wf_fb_logsum in its forward (grad_scale[b] = -w_b, the reduction's own
+ * factor) and keeps the gradient for backward, which only has to multiply it by the upstream gradient:
+ * wf_loss_reduce: out[0] = sum_b w[b] * (-tot[b]) (w NULL: 1) -- 'sum', and 'mean' with w[b] = 1 / (B * target_len[b]).
+ * wf_grad_scale: grad[., ., label columns of the utterance's graph] *= gs[u] (per_utt) or gs[0]; wavefronts whose
+ * factor is exactly 1 -- the usual loss.backward() -- exit at once.  Must follow the wf_fb_logsum(grad != NULL) call
+ * with the same graph / seg / workspace on the same stream (reads the tables it left there).  gs: DEVICE fp32.   */
+int wf_loss_reduce(const float* tot, const float* w, int32_t B, float* out, void* stream);
+int wf_grad_scale(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const int32_t* seg,
+                  int32_t B, int32_t num_seqs, int32_t Tmax, int32_t V, int64_t strideB, int64_t strideT,
+                  const float* gs, int32_t per_utt, float* grad, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- state posteriors (waterfall/manual_ctc/prior.py:4-55 compute_align) -----------------------
  * Must follow a wf_fb_logsum(..., flags | WF_KEEP_AB, same graph / seg / workspace) on the same stream.

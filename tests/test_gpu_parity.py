@@ -22,15 +22,21 @@ TOPO_CASES = ["2state", "2state-1", "3state-skip", "3state-skip-1", "3state-skip
               "2state_sil", "mmictc_noblk"]
 
 
-def run_hip(fsa, lp, segs, reduction="none", target_lengths=None, use_double=False, need_grad=True):
+def run_hip(fsa, lp, segs, reduction="none", target_lengths=None, use_double=False, need_grad=True, eager=True):
+    """graphloss + backward under autograd.  eager (the default of the drop-in): loss and gradient by the fused call in
+    forward for graphs with compact label columns; eager=False: the forward / backward split (two C calls)."""
     x = torch.from_numpy(np.ascontiguousarray(lp)).to(DEV).requires_grad_(need_grad)
     dense = wf.DenseFsaVec(x, torch.from_numpy(np.ascontiguousarray(segs, dtype=np.int32)))
-    loss = wf.graphloss(fsa, dense, output_beam=10, reduction=reduction, use_double_scores=use_double,
-                        target_lengths=target_lengths)
-    grad = None
-    if need_grad:
-        (loss.sum() if reduction == "none" else loss).backward()
-        grad = x.grad.cpu().numpy()
+    wf.set_eager_gradient(eager)
+    try:
+        loss = wf.graphloss(fsa, dense, output_beam=10, reduction=reduction, use_double_scores=use_double,
+                            target_lengths=target_lengths)
+        grad = None
+        if need_grad:
+            (loss.sum() if reduction == "none" else loss).backward()
+            grad = x.grad.cpu().numpy()
+    finally:
+        wf.set_eager_gradient(True)
     return loss.detach().cpu().numpy(), grad
 
 
@@ -81,11 +87,39 @@ def test_every_topology_numerator_and_denominator(topo, den):
     check_against_oracle(c)
 
 
+@pytest.mark.parametrize("eager", [True, False])
 @pytest.mark.parametrize("reduction", ["none", "sum", "mean"])
-def test_reductions_match_graph_py(reduction):
+def test_reductions_match_graph_py(reduction, eager):
     c = util.random_case(7, "2state", B=5, T=30, L=4, P=6)
     tl = torch.tensor([len(s) for s in c["seqs"]], dtype=torch.float32)
-    check_against_oracle(c, reduction, target_lengths=tl if reduction == "mean" else None)
+    tlen = tl if reduction == "mean" else None
+    loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], reduction, tlen, eager=eager)
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, reduction, None if tlen is None else tlen.numpy())
+    np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+
+
+def test_eager_gradient_upstream_factors_and_numerator_minus_denominator():
+    # loss = 0.25 * (numerator - denominator) (models.py:338-340 shape): the numerator's eager gradient is scaled by the
+    # upstream factor in backward; per-utterance factors with reduction 'none'
+    c = util.random_case(15, "mmictc", B=4, T=36, L=5, P=7)
+    d = util.random_case(15, "mmictc", B=4, T=36, L=5, P=7, den=True)
+    x = torch.from_numpy(c["lp"]).to(DEV).requires_grad_(True)
+    dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
+    num = wf.graphloss(c["fsa"], dense, reduction="sum")
+    den = wf.graphloss(d["fsa"], dense, reduction="sum")
+    (0.25 * (num - den)).backward()
+    wn, gn = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "sum")
+    wd, gd = o.graphloss(d["ographs"], c["lp"], c["segs"], None, "sum")
+    np.testing.assert_allclose(num.item(), wn, rtol=TOT_RTOL)
+    np.testing.assert_allclose(den.item(), wd, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), 0.25 * (gn - gd), atol=GRAD_ATOL)
+    x2 = torch.from_numpy(c["lp"]).to(DEV).requires_grad_(True)
+    per = wf.graphloss(c["fsa"], wf.DenseFsaVec(x2, torch.from_numpy(c["segs"])), reduction="none")
+    f = torch.tensor([1.0, -2.0, 0.5, 1.0], device=DEV)
+    (per * f).sum().backward()
+    _, g_none = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    np.testing.assert_allclose(x2.grad.cpu().numpy(), g_none * f.cpu().numpy()[:, None, None], atol=2 * GRAD_ATOL)
 
 
 def test_double_scores():
@@ -381,9 +415,10 @@ def test_sweep_paths_fused_and_autograd(path, topo, den, L, T, P):
     def run():
         tot, grad = fused_logsum(c["fsa"], c["lp"], c["segs"])
         loss, agrad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
-        return tot, grad, loss, agrad
-    tot, grad, loss, agrad = _with_env(SWEEP_PATHS[path], run)
-    for got_loss, got_grad in ((-tot, grad), (loss, agrad)):
+        loss2, agrad2 = run_hip(c["fsa"], c["lp"], c["segs"], "none", eager=False)
+        return tot, grad, loss, agrad, loss2, agrad2
+    tot, grad, loss, agrad, loss2, agrad2 = _with_env(SWEEP_PATHS[path], run)
+    for got_loss, got_grad in ((-tot, grad), (loss, agrad), (loss2, agrad2)):
         assert np.array_equal(np.isfinite(got_loss), ok)
         np.testing.assert_allclose(got_loss[ok], want[ok], rtol=TOT_RTOL, atol=TOT_ATOL)
         np.testing.assert_allclose(got_grad, wgrad, atol=GRAD_ATOL)

@@ -45,12 +45,14 @@ _SIGS = {
     "wf_compose_linear": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, C.POINTER(_i32), C.POINTER(_i32), _i32]),
     "wf_compose_fsa_batch": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, C.c_int64, _p, _p]),
     "wf_loss_stats": (C.c_int, [_p, _i32, C.c_float, _p, _p]),
-    "wf_topo_index_words": (C.c_int, [_i32, _i32, C.POINTER(C.c_int64)]),
+    "wf_topo_index_words": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(C.c_int64)]),
     "wf_topo_index_build": (C.c_int, [_p, _p, _i32, _i32, _p]),
     "wf_compose_linear_batch": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _i32, _p, _p, C.c_int64, _p, _p]),
     "wf_init": (C.c_int, []),
     "wf_shutdown": (C.c_int, []),
     "wf_debug_reload_env": (C.c_int, []),
+    "wf_numerator_compile": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _i32, _p, _p, C.c_int64, _p, _p,
+                                       _p, _sz, C.POINTER(_sz), _i32]),
     "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),
     "wf_static_scratch_bytes": (C.c_int, [C.POINTER(_sz)]),
     "wf_fb_logsum_static": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, C.c_float, _u32,
@@ -59,6 +61,8 @@ _SIGS = {
                                _p, _p, _p, _p, _sz, _p]),
     "wf_fb_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, _u32,
                                  _p, _p, _p, _p, _sz, _p]),
+    "wf_loss_reduce": (C.c_int, [_p, _p, _i32, _p, _p]),
+    "wf_grad_scale": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _p, _i32, _p, _p, _sz, _p]),
     "wf_state_posteriors": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _u32, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
     "wf_tot_scores": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _u32, _p, _p, _sz, _p]),
     "wf_timing_enable": (C.c_int, [C.c_int]),

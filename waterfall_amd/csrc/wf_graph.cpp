@@ -11,8 +11,13 @@
 #include <cstdio>
 #include <climits>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
+#include <functional>
+#include <mutex>
 #include <numeric>
+#include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -34,74 +39,306 @@ int wf_fail(int code, const char* fmt, ...) {
 
 namespace {
 
-struct FsaPlan {
-    int S = 0, A = 0, NF = 0, K = 0, direct = 0, max_label = -1;
-    std::vector<int> em;   // emitting arc ids (local)
-    std::vector<int> fin;  // final arc ids (local)
-    size_t words = 0;
-};
-
 inline size_t pad4(size_t w) { return (w + 3) & ~size_t(3); }
 
-// Validates FSA g and computes its size.
-int plan_fsa(const wf_graph_host* gh, int g, FsaPlan* p, std::vector<int>* labels_sorted) {
+// Upper bound of the words FSA g takes in the blob, from its arc and state counts alone (O(1): no pass over the arcs).
+// K <= 2A + 1: compact columns K <= A; direct columns K = max_label + 1 <= 2 * (#distinct labels).
+inline size_t fsa_words_bound(size_t S, size_t A) {
+    const size_t K = 2 * A + 1;
+    size_t w = 0;
+    w += pad4(S + 1) + 4 * pad4(A);          // in_off, in_src, in_col, in_w, in_arc
+    w += pad4(S + 1) + 3 * pad4(A);          // out_off, out_dst, out_col, out_w
+    w += pad4(K + 1) + 4 * pad4(A);          // lab_off, lab_src, lab_dst, lab_w, lab_col
+    w += pad4(K);                            // labels
+    w += 3 * pad4(A);                        // fin_src, fin_w, fin_arc (NF <= A)
+    w += 2 * pad4(S);                        // heavy_in, heavy_out
+    w += 2 * pad4(S) + pad4(A);              // finb_log, finb_max, arc_src
+    if (S - 1 <= 64 * WF_BAND_MAX_R)         // banded form is only built for graphs one wavefront can hold
+        w += pad4(S) + 2 * pad4(S * (WF_BAND_MAX_BW + 1) * WF_BAND_MAX_M * 2);
+    return w;
+}
+
+// Scratch reused across the FSAs of a call and across calls of a host thread: no heap traffic per graph.
+struct PrepScratch {
+    std::vector<int32_t> em, fin, col, labs, cnt, pos, colmap, stamp, indeg, order, qbuf, dist, fillf, fillb;
+    std::vector<double> fm, fs;
+    int32_t epoch = 0;
+};
+thread_local PrepScratch g_prep;
+
+// Builds FSA g's tables at blob word `cur` (advanced past them).  I: its info words.
+int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& cur, size_t limit, int* out_maxlab) {
+    PrepScratch& X = g_prep;
     const int a0 = gh->fsa_arc_offsets[g], a1 = gh->fsa_arc_offsets[g + 1];
     const int S = gh->fsa_num_states[g];
     if (a1 < a0) return wf_fail(WF_EINVAL, "fsa %d: arc offsets not monotone", g);
     if (S < 2) return wf_fail(WF_EINVAL, "fsa %d: needs at least a start and a final state (S=%d)", g, S);
-    p->S = S;
-    std::vector<int> labs;
-    for (int a = a0; a < a1; ++a) {
-        const int32_t* r = gh->arcs + 4 * (size_t)a;
+    const int32_t* arcs = gh->arcs + 4 * (size_t)a0;
+    const int NA = a1 - a0;
+    // ---- validation, emitting / final split, distinct labels
+    X.em.clear(); X.fin.clear(); X.labs.clear();
+    int max_label = -1;
+    for (int a = 0; a < NA; ++a) {
+        const int32_t* r = arcs + 4 * (size_t)a;
         if (r[0] < 0 || r[0] >= S || r[1] < 0 || r[1] >= S)
-            return wf_fail(WF_ERANGE, "fsa %d arc %d: state out of range (%d -> %d, S=%d)", g, a - a0, r[0], r[1], S);
-        if (r[2] < -1) return wf_fail(WF_ERANGE, "fsa %d arc %d: label %d < -1", g, a - a0, r[2]);
+            return wf_fail(WF_ERANGE, "fsa %d arc %d: state out of range (%d -> %d, S=%d)", g, a, r[0], r[1], S);
+        if (r[2] < -1) return wf_fail(WF_ERANGE, "fsa %d arc %d: label %d < -1", g, a, r[2]);
         if (r[2] == -1) {
-            if (r[1] != S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: label -1 arc must enter the final state", g, a - a0);
-            p->fin.push_back(a - a0);
+            if (r[1] != S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: label -1 arc must enter the final state", g, a);
+            X.fin.push_back(a);
         } else {
-            if (r[1] == S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: only label -1 arcs may enter the final state", g, a - a0);
-            if (r[0] == S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: arc leaves the final state", g, a - a0);
-            p->em.push_back(a - a0);
-            labs.push_back(r[2]);
-            p->max_label = std::max(p->max_label, (int)r[2]);
+            if (r[1] == S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: only label -1 arcs may enter the final state", g, a);
+            if (r[0] == S - 1) return wf_fail(WF_EINVAL, "fsa %d arc %d: arc leaves the final state", g, a);
+            X.em.push_back(a);
+            max_label = std::max(max_label, (int)r[2]);
         }
     }
-    p->A = (int)p->em.size();
-    p->NF = (int)p->fin.size();
-    std::sort(labs.begin(), labs.end());
-    labs.erase(std::unique(labs.begin(), labs.end()), labs.end());
+    const int A = (int)X.em.size(), NF = (int)X.fin.size();
+    // label -> column through a stamped table (no search per arc)
+    if ((int)X.stamp.size() < max_label + 1) { X.stamp.resize(max_label + 1, 0); X.colmap.resize(max_label + 1, 0); }
+    if (++X.epoch == INT32_MAX) { std::fill(X.stamp.begin(), X.stamp.end(), 0); X.epoch = 1; }
+    for (int a : X.em) {
+        const int l = arcs[4 * (size_t)a + 2];
+        if (X.stamp[l] != X.epoch) { X.stamp[l] = X.epoch; X.labs.push_back(l); }
+    }
+    std::sort(X.labs.begin(), X.labs.end());
     // direct columns when the graph uses at least half of the label range (topologies used as
     // denominators use every token): emissions are then read straight from log_probs.
-    p->direct = (p->max_label >= 0 && (size_t)labs.size() * 2 >= (size_t)p->max_label + 1) ? 1 : 0;
-    p->K = p->direct ? p->max_label + 1 : (int)labs.size();
-    if (labels_sorted) *labels_sorted = labs;
-    size_t w = 0;
-    w += pad4(S + 1) + 4 * pad4(p->A);          // in_off, in_src, in_col, in_w, in_arc
-    w += pad4(S + 1) + 3 * pad4(p->A);          // out_off, out_dst, out_col, out_w
-    w += pad4(p->K + 1) + 4 * pad4(p->A);       // lab_off, lab_src, lab_dst, lab_w, lab_col
-    w += pad4(p->K);                            // labels
-    w += 3 * pad4(p->NF);                       // fin_src, fin_w, fin_arc
-    w += 2 * pad4(S);                           // heavy_in, heavy_out (upper bound)
-    w += 2 * pad4(S) + pad4(p->A + p->NF);      // finb_log, finb_max, arc_src
-    if (S - 1 <= 64 * WF_BAND_MAX_R)   // banded form is only built for graphs one wavefront can hold
-        w += pad4(S) + 2 * pad4((size_t)S * (WF_BAND_MAX_BW + 1) * WF_BAND_MAX_M * 2);   // order + two tables (upper bound)
-    p->words = w;
+    const int direct = (max_label >= 0 && X.labs.size() * 2 >= (size_t)max_label + 1) ? 1 : 0;
+    const int K = direct ? max_label + 1 : (int)X.labs.size();
+    if (!direct) for (int k = 0; k < K; ++k) X.colmap[X.labs[k]] = k;
+    X.col.resize(A);
+    for (int j = 0; j < A; ++j) { const int l = arcs[4 * (size_t)X.em[j] + 2]; X.col[j] = direct ? l : X.colmap[l]; }
+    *out_maxlab = max_label;
+
+    auto take = [&](size_t n) { size_t o = cur; cur += pad4(n); return (int32_t)o; };
+    memset(I, 0, sizeof(int32_t) * WF_INFO_WORDS);
+    I[WF_I_S] = S; I[WF_I_A] = A; I[WF_I_NF] = NF; I[WF_I_K] = K; I[WF_I_DIRECT] = direct;
+    I[WF_I_ARC_BASE] = a0;
+    I[WF_I_MAX_LABEL] = max_label;
+    const size_t need = 2 * pad4(S + 1) + 11 * pad4(A) + pad4(K + 1) + pad4(K) + 3 * pad4(NF) + 4 * pad4(S) + pad4(A + NF);
+    if (cur + need > limit) return wf_fail(WF_ENOSPC, "wf_graph_prepare: blob too small at fsa %d", g);
+    X.cnt.assign(std::max(S, K) + 1, 0);
+    X.pos.resize(std::max(S, K) + 1);
+    int we = 1;
+    // ---- incoming CSR: stable sort of emitting arcs by dst
+    {
+        int o_off = take(S + 1), o_src = take(A), o_col = take(A), o_w = take(A), o_arc = take(A);
+        I[WF_I_IN_OFF] = o_off; I[WF_I_IN_SRC] = o_src; I[WF_I_IN_COL] = o_col; I[WF_I_IN_W] = o_w; I[WF_I_IN_ARC] = o_arc;
+        int32_t* cnt = X.cnt.data();
+        std::fill(cnt, cnt + S + 1, 0);
+        for (int a : X.em) cnt[arcs[4 * (size_t)a + 1] + 1]++;
+        for (int s2 = 0; s2 < S; ++s2) cnt[s2 + 1] += cnt[s2];
+        memcpy(B + o_off, cnt, sizeof(int32_t) * (S + 1));
+        int32_t* pos = X.pos.data();
+        memcpy(pos, cnt, sizeof(int32_t) * S);
+        for (int j = 0; j < A; ++j) {
+            const int32_t* r = arcs + 4 * (size_t)X.em[j];
+            const int q = pos[r[1]]++;
+            B[o_src + q] = r[0];
+            B[o_col + q] = X.col[j];
+            B[o_w + q] = r[3];
+            B[o_arc + q] = X.em[j];
+            if (r[3] != 0 && r[3] != (int32_t)0x80000000) we = 0;   // weight != +-0.0
+        }
+        int o_h = take(S), nh = 0, maxin = 0, nover = 0, over = 0;
+        for (int s2 = 0; s2 < S; ++s2) {
+            const int deg = cnt[s2 + 1] - cnt[s2];
+            maxin = std::max(maxin, deg);
+            if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s2;
+            if (deg > WF_REG_DEG) { ++nover; over = s2; }
+        }
+        I[WF_I_HEAVY_IN] = o_h; I[WF_I_NHEAVY_IN] = nh; I[WF_I_MAXIN] = maxin;
+        I[WF_I_NOVER_IN] = nover; I[WF_I_OVER_IN] = over;
+    }
+    // ---- outgoing CSR: emitting arcs in original order grouped by src (stable)
+    {
+        int o_off = take(S + 1), o_dst = take(A), o_col = take(A), o_w = take(A);
+        I[WF_I_OUT_OFF] = o_off; I[WF_I_OUT_DST] = o_dst; I[WF_I_OUT_COL] = o_col; I[WF_I_OUT_W] = o_w;
+        int32_t* cnt = X.cnt.data();
+        std::fill(cnt, cnt + S + 1, 0);
+        for (int a : X.em) cnt[arcs[4 * (size_t)a] + 1]++;
+        for (int s2 = 0; s2 < S; ++s2) cnt[s2 + 1] += cnt[s2];
+        memcpy(B + o_off, cnt, sizeof(int32_t) * (S + 1));
+        int32_t* pos = X.pos.data();
+        memcpy(pos, cnt, sizeof(int32_t) * S);
+        for (int j = 0; j < A; ++j) {
+            const int32_t* r = arcs + 4 * (size_t)X.em[j];
+            const int q = pos[r[0]]++;
+            B[o_dst + q] = r[1];
+            B[o_col + q] = X.col[j];
+            B[o_w + q] = r[3];
+        }
+        int o_h = take(S), nh = 0, maxout = 0, nover = 0, over = 0;
+        for (int s2 = 0; s2 < S; ++s2) {
+            const int deg = cnt[s2 + 1] - cnt[s2];
+            maxout = std::max(maxout, deg);
+            if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s2;
+            if (deg > WF_REG_DEG) { ++nover; over = s2; }
+        }
+        I[WF_I_HEAVY_OUT] = o_h; I[WF_I_NHEAVY_OUT] = nh; I[WF_I_MAXOUT] = maxout;
+        I[WF_I_NOVER_OUT] = nover; I[WF_I_OVER_OUT] = over;
+    }
+    // ---- label(column)-sorted arcs
+    {
+        int o_off = take(K + 1), o_src = take(A), o_dst = take(A), o_w = take(A), o_lab = take(K), o_lcol = take(A);
+        I[WF_I_LAB_COL] = o_lcol;
+        I[WF_I_LAB_OFF] = o_off; I[WF_I_LAB_SRC] = o_src; I[WF_I_LAB_DST] = o_dst; I[WF_I_LAB_W] = o_w; I[WF_I_LABELS] = o_lab;
+        int32_t* cnt = X.cnt.data();
+        std::fill(cnt, cnt + K + 1, 0);
+        for (int j = 0; j < A; ++j) cnt[X.col[j] + 1]++;
+        int maxdeg = 0;
+        for (int k = 0; k < K; ++k) { maxdeg = std::max(maxdeg, cnt[k + 1]); cnt[k + 1] += cnt[k]; }
+        memcpy(B + o_off, cnt, sizeof(int32_t) * (K + 1));
+        int32_t* pos = X.pos.data();
+        memcpy(pos, cnt, sizeof(int32_t) * K);
+        for (int j = 0; j < A; ++j) {
+            const int32_t* r = arcs + 4 * (size_t)X.em[j];
+            const int q = pos[X.col[j]]++;
+            B[o_src + q] = r[0];
+            B[o_dst + q] = r[1];
+            B[o_w + q] = r[3];
+            B[o_lcol + q] = X.col[j];
+        }
+        for (int k = 0; k < K; ++k) B[o_lab + k] = direct ? k : X.labs[k];
+        I[WF_I_MAXLAB_DEG] = maxdeg;
+    }
+    // ---- final arcs
+    {
+        int o_src = take(NF), o_w = take(NF), o_arc = take(NF);
+        I[WF_I_FIN_SRC] = o_src; I[WF_I_FIN_W] = o_w; I[WF_I_FIN_ARC] = o_arc;
+        for (int i = 0; i < NF; ++i) {
+            const int a = X.fin[i];
+            B[o_src + i] = arcs[4 * (size_t)a];
+            B[o_w + i] = arcs[4 * (size_t)a + 3];
+            B[o_arc + i] = a;
+        }
+    }
+    // ---- beta_T per state and the source state of every original arc
+    {
+        int o_fl = take(S), o_fm = take(S), o_as = take(A + NF);
+        I[WF_I_FINB_LOG] = o_fl; I[WF_I_FINB_MAX] = o_fm; I[WF_I_ARC_SRC] = o_as;
+        const float ninf = -INFINITY;
+        int32_t nbits; memcpy(&nbits, &ninf, 4);
+        for (int s2 = 0; s2 < S; ++s2) { B[o_fl + s2] = nbits; B[o_fm + s2] = nbits; }
+        bool single = true;   // at most one final arc per state (every topology here): beta_T = its weight
+        for (int a : X.fin) {
+            const int s2 = arcs[4 * (size_t)a];
+            if (B[o_fm + s2] != nbits) { single = false; break; }
+            B[o_fm + s2] = arcs[4 * (size_t)a + 3];
+            B[o_fl + s2] = arcs[4 * (size_t)a + 3];
+        }
+        if (!single) {
+            X.fm.assign(S, -INFINITY); X.fs.assign(S, 0.0);
+            for (int a : X.fin) { float w; memcpy(&w, &arcs[4 * (size_t)a + 3], 4); X.fm[arcs[4 * (size_t)a]] = std::max(X.fm[arcs[4 * (size_t)a]], (double)w); }
+            for (int a : X.fin) { float w; memcpy(&w, &arcs[4 * (size_t)a + 3], 4); X.fs[arcs[4 * (size_t)a]] += std::exp((double)w - X.fm[arcs[4 * (size_t)a]]); }
+            for (int s2 = 0; s2 < S; ++s2) {
+                const float fl = (X.fm[s2] == -INFINITY) ? -INFINITY : (float)(X.fm[s2] + std::log(X.fs[s2]));
+                const float fm = (float)X.fm[s2];
+                memcpy(&B[o_fl + s2], &fl, 4);
+                memcpy(&B[o_fm + s2], &fm, 4);
+            }
+        }
+        for (int a = 0; a < A + NF; ++a) B[o_as + a] = arcs[4 * (size_t)a];
+    }
+    const int32_t* ooff = B + I[WF_I_OUT_OFF];
+    const int32_t* odst = B + I[WF_I_OUT_DST];
+    // ---- fewest frames any accepted path needs (BFS over emitting arcs from the start state)
+    {
+        X.dist.assign(S, -1);
+        X.qbuf.resize(S);
+        int32_t* dist = X.dist.data();
+        for (int a : X.fin) if (dist[arcs[4 * (size_t)a]] == -1) dist[arcs[4 * (size_t)a]] = -2;   // -2: unvisited, has a final arc
+        int qh = 0, qt = 0, minlen = INT32_MAX;
+        const bool start_final = dist[0] == -2;
+        dist[0] = 0; X.qbuf[qt++] = 0;
+        if (start_final) minlen = 0;
+        while (qh < qt && minlen == INT32_MAX) {
+            const int s2 = X.qbuf[qh++];
+            for (int e = ooff[s2]; e < ooff[s2 + 1]; ++e) {
+                const int d = odst[e];
+                if (dist[d] >= 0) continue;
+                const bool fin_here = dist[d] == -2;
+                dist[d] = dist[s2] + 1;
+                if (fin_here) { minlen = std::min(minlen, dist[d]); }
+                X.qbuf[qt++] = d;
+            }
+        }
+        I[WF_I_MINLEN] = minlen;
+    }
+    // ---- banded form: Kahn topological order (FIFO, self-loops ignored) of the non-final states
+    {
+        const int Sn = S - 1;   // the super-final state has no emitting arcs
+        I[WF_I_BAND_BW] = -1; I[WF_I_BAND_M] = 0;
+        I[WF_I_BAND_WE] = we;
+        if (Sn >= 1 && Sn <= 64 * WF_BAND_MAX_R) {
+            X.indeg.assign(Sn, 0); X.order.clear(); X.pos.resize(std::max(std::max(S, K) + 1, Sn));
+            int32_t* pos = X.pos.data();
+            for (int s2 = 0; s2 < Sn; ++s2)
+                for (int e = ooff[s2]; e < ooff[s2 + 1]; ++e)
+                    if (odst[e] != s2) X.indeg[odst[e]]++;
+            X.qbuf.resize(S);
+            int qh = 0, qt = 0;
+            for (int s2 = 0; s2 < Sn; ++s2) if (X.indeg[s2] == 0) X.qbuf[qt++] = s2;
+            while (qh < qt) {
+                const int s2 = X.qbuf[qh++];
+                pos[s2] = (int)X.order.size(); X.order.push_back(s2);
+                for (int e = ooff[s2]; e < ooff[s2 + 1]; ++e)
+                    if (odst[e] != s2 && --X.indeg[odst[e]] == 0) X.qbuf[qt++] = odst[e];
+            }
+            if ((int)X.order.size() == Sn) {
+                int bw = 0;
+                for (int a : X.em) bw = std::max(bw, pos[arcs[4 * (size_t)a + 1]] - pos[arcs[4 * (size_t)a]]);
+                // arcs per (destination position, distance) cell
+                int m = 0;
+                if (bw <= WF_BAND_MAX_BW) {
+                    X.fillf.assign((size_t)Sn * (bw + 1), 0);
+                    for (int a : X.em) {
+                        const int pd = pos[arcs[4 * (size_t)a + 1]], d = pd - pos[arcs[4 * (size_t)a]];
+                        m = std::max(m, ++X.fillf[(size_t)pd * (bw + 1) + d]);
+                    }
+                }
+                if (bw <= WF_BAND_MAX_BW && m <= WF_BAND_MAX_M) {
+                    m = std::max(m, 1);
+                    const size_t cells = (size_t)Sn * (bw + 1) * m;
+                    if (cur + pad4(Sn) + 2 * pad4(cells * 2) > limit) return wf_fail(WF_ENOSPC, "wf_graph_prepare: blob too small at fsa %d (band tables)", g);
+                    int o_ord = take(Sn), o_f = take(cells * 2), o_b = take(cells * 2);
+                    I[WF_I_BAND_BW] = bw; I[WF_I_BAND_M] = m; I[WF_I_BAND_ORDER] = o_ord; I[WF_I_BANDF] = o_f; I[WF_I_BANDB] = o_b;
+                    memcpy(B + o_ord, X.order.data(), sizeof(int32_t) * Sn);
+                    // empty cells: column 0, weight -inf (probability 0)
+                    const float ninf = -INFINITY; int32_t nbits; memcpy(&nbits, &ninf, 4);
+                    for (size_t c = 0; c < cells; ++c) { B[o_f + 2 * c] = 0; B[o_f + 2 * c + 1] = nbits; B[o_b + 2 * c] = 0; B[o_b + 2 * c + 1] = nbits; }
+                    X.fillf.assign((size_t)Sn * (bw + 1), 0); X.fillb.assign((size_t)Sn * (bw + 1), 0);
+                    for (int j = 0; j < A; ++j) {
+                        const int32_t* r = arcs + 4 * (size_t)X.em[j];
+                        const int ps = pos[r[0]], pd = pos[r[1]], d = pd - ps;
+                        const int col = X.col[j];
+                        const size_t cf = (size_t)pd * (bw + 1) + d;
+                        const size_t ef = cf * m + X.fillf[cf]++;
+                        B[o_f + 2 * ef] = col; B[o_f + 2 * ef + 1] = r[3];
+                        const size_t cb = (size_t)(Sn - 1 - ps) * (bw + 1) + d;
+                        const size_t eb = cb * m + X.fillb[cb]++;
+                        B[o_b + 2 * eb] = col; B[o_b + 2 * eb + 1] = r[3];
+                    }
+                }
+            }
+        }
+    }
     return WF_OK;
 }
 
 }  // namespace
 
+// An upper bound that needs no pass over the arcs (wf_graph_prepare fills B[WF_H_WORDS] with the words actually used:
+// only those need to travel to the device).
 extern "C" int wf_graph_prepare_bytes(const wf_graph_host* g, size_t* bytes) {
     if (!g || !bytes || g->num_fsas < 1 || !g->arcs || !g->fsa_arc_offsets || !g->fsa_num_states)
         return wf_fail(WF_EINVAL, "wf_graph_prepare_bytes: null or empty graph");
-    size_t w = WF_HDR_WORDS + (size_t)WF_INFO_WORDS * g->num_fsas;
-    w = pad4(w);
+    size_t w = pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * g->num_fsas);
     for (int i = 0; i < g->num_fsas; ++i) {
-        FsaPlan p;
-        int rc = plan_fsa(g, i, &p, nullptr);
-        if (rc) return rc;
-        w += p.words;
+        const int na = g->fsa_arc_offsets[i + 1] - g->fsa_arc_offsets[i];
+        if (na < 0 || g->fsa_num_states[i] < 2) return wf_fail(WF_EINVAL, "fsa %d: bad arc offsets or fewer than two states", i);
+        w += fsa_words_bound((size_t)g->fsa_num_states[i], (size_t)na);
     }
     if (w >= (size_t)1 << 31) return wf_fail(WF_EUNSUPPORTED, "prepared graph exceeds 2^31 words");
     *bytes = w * 4;
@@ -109,231 +346,25 @@ extern "C" int wf_graph_prepare_bytes(const wf_graph_host* g, size_t* bytes) {
 }
 
 extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t bytes) {
-    size_t need = 0;
-    int rc = wf_graph_prepare_bytes(gh, &need);
-    if (rc) return rc;
-    if (!blob_host || bytes < need) return wf_fail(WF_ENOSPC, "wf_graph_prepare: blob too small (%zu < %zu)", bytes, need);
-    int32_t* B = (int32_t*)blob_host;
-    memset(B, 0, need);
-    B[WF_H_MAGIC] = WF_BLOB_MAGIC;
-    B[WF_H_NUM_FSAS] = gh->num_fsas;
-    B[WF_H_WORDS] = (int32_t)(need / 4);
-    int gmaxlab = -1, gmaxS = 0, gmaxA = 0;
-    // plans (validation, sizes) first: every graph's region of the blob is known before its tables are built
+    if (!gh || gh->num_fsas < 1 || !gh->arcs || !gh->fsa_arc_offsets || !gh->fsa_num_states)
+        return wf_fail(WF_EINVAL, "wf_graph_prepare: null or empty graph");
     const int G = gh->num_fsas;
-    std::vector<FsaPlan> plans(G);
-    std::vector<std::vector<int>> all_labs(G);
-    std::vector<size_t> start(G + 1);
-    start[0] = pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * G);
+    size_t cur = pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * G);
+    if (!blob_host || bytes < cur * 4) return wf_fail(WF_ENOSPC, "wf_graph_prepare: blob too small (%zu B)", bytes);
+    int32_t* B = (int32_t*)blob_host;
+    const size_t limit = std::min(bytes / 4, (size_t)INT32_MAX);
+    memset(B, 0, sizeof(int32_t) * WF_HDR_WORDS);
+    B[WF_H_MAGIC] = WF_BLOB_MAGIC;
+    B[WF_H_NUM_FSAS] = G;
+    int gmaxlab = -1, gmaxS = 0, gmaxA = 0;
     for (int g = 0; g < G; ++g) {
-        rc = plan_fsa(gh, g, &plans[g], &all_labs[g]);
-        if (rc) return rc;
-        start[g + 1] = start[g] + plans[g].words;
-        gmaxlab = std::max(gmaxlab, plans[g].max_label); gmaxS = std::max(gmaxS, plans[g].S); gmaxA = std::max(gmaxA, plans[g].A);
-    }
-    if (start[G] * 4 > need) return wf_fail(WF_ENOSPC, "internal: blob overflow");
-    for (int g = 0; g < G; ++g) {
-        const FsaPlan& p = plans[g];
-        const std::vector<int>& labs = all_labs[g];
-        size_t cur = start[g];
         int32_t* I = B + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * g;
-        const int32_t* arcs = gh->arcs + 4 * (size_t)gh->fsa_arc_offsets[g];
-        const int S = p.S, A = p.A;
-        auto take = [&](size_t n) { size_t o = cur; cur += pad4(n); return (int32_t)o; };
-        I[WF_I_S] = S; I[WF_I_A] = A; I[WF_I_NF] = p.NF; I[WF_I_K] = p.K; I[WF_I_DIRECT] = p.direct;
-        I[WF_I_ARC_BASE] = gh->fsa_arc_offsets[g];
-        I[WF_I_MAX_LABEL] = p.max_label;
-        auto col_of = [&](int label) {
-            if (p.direct) return label;
-            return (int)(std::lower_bound(labs.begin(), labs.end(), label) - labs.begin());
-        };
-        // ---- incoming CSR: stable sort of emitting arcs by dst
-        {
-            int o_off = take(S + 1), o_src = take(A), o_col = take(A), o_w = take(A), o_arc = take(A);
-            I[WF_I_IN_OFF] = o_off; I[WF_I_IN_SRC] = o_src; I[WF_I_IN_COL] = o_col; I[WF_I_IN_W] = o_w; I[WF_I_IN_ARC] = o_arc;
-            std::vector<int> cnt(S + 1, 0);
-            for (int a : p.em) cnt[arcs[4 * a + 1] + 1]++;
-            for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
-            memcpy(B + o_off, cnt.data(), sizeof(int) * (S + 1));
-            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-            int maxin = 0;
-            for (int a : p.em) {
-                int d = arcs[4 * a + 1];
-                int q = pos[d]++;
-                B[o_src + q] = arcs[4 * a + 0];
-                B[o_col + q] = col_of(arcs[4 * a + 2]);
-                B[o_w + q] = arcs[4 * a + 3];
-                B[o_arc + q] = a;
-            }
-            int o_h = take(S), nh = 0;
-            for (int s = 0; s < S; ++s) {
-                int deg = cnt[s + 1] - cnt[s];
-                maxin = std::max(maxin, deg);
-                if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s;
-            }
-            I[WF_I_HEAVY_IN] = o_h; I[WF_I_NHEAVY_IN] = nh; I[WF_I_MAXIN] = maxin;
-            int nover = 0, over = 0;
-            for (int s = 0; s < S; ++s) if (cnt[s + 1] - cnt[s] > WF_REG_DEG) { ++nover; over = s; }
-            I[WF_I_NOVER_IN] = nover; I[WF_I_OVER_IN] = over;
-        }
-        // ---- outgoing CSR: emitting arcs in original order grouped by src (stable)
-        {
-            int o_off = take(S + 1), o_dst = take(A), o_col = take(A), o_w = take(A);
-            I[WF_I_OUT_OFF] = o_off; I[WF_I_OUT_DST] = o_dst; I[WF_I_OUT_COL] = o_col; I[WF_I_OUT_W] = o_w;
-            std::vector<int> cnt(S + 1, 0);
-            for (int a : p.em) cnt[arcs[4 * a + 0] + 1]++;
-            for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
-            memcpy(B + o_off, cnt.data(), sizeof(int) * (S + 1));
-            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-            int maxout = 0;
-            for (int a : p.em) {
-                int s = arcs[4 * a + 0];
-                int q = pos[s]++;
-                B[o_dst + q] = arcs[4 * a + 1];
-                B[o_col + q] = col_of(arcs[4 * a + 2]);
-                B[o_w + q] = arcs[4 * a + 3];
-            }
-            int o_h = take(S), nh = 0;
-            for (int s = 0; s < S; ++s) {
-                int deg = cnt[s + 1] - cnt[s];
-                maxout = std::max(maxout, deg);
-                if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s;
-            }
-            I[WF_I_HEAVY_OUT] = o_h; I[WF_I_NHEAVY_OUT] = nh; I[WF_I_MAXOUT] = maxout;
-            int nover = 0, over = 0;
-            for (int s = 0; s < S; ++s) if (cnt[s + 1] - cnt[s] > WF_REG_DEG) { ++nover; over = s; }
-            I[WF_I_NOVER_OUT] = nover; I[WF_I_OVER_OUT] = over;
-        }
-        // ---- label(column)-sorted arcs
-        {
-            const int K = p.K;
-            int o_off = take(K + 1), o_src = take(A), o_dst = take(A), o_w = take(A), o_lab = take(K), o_lcol = take(A);
-            I[WF_I_LAB_COL] = o_lcol;
-            I[WF_I_LAB_OFF] = o_off; I[WF_I_LAB_SRC] = o_src; I[WF_I_LAB_DST] = o_dst; I[WF_I_LAB_W] = o_w; I[WF_I_LABELS] = o_lab;
-            std::vector<int> cnt(K + 1, 0);
-            for (int a : p.em) cnt[col_of(arcs[4 * a + 2]) + 1]++;
-            int maxdeg = 0;
-            for (int k = 0; k < K; ++k) { maxdeg = std::max(maxdeg, cnt[k + 1]); cnt[k + 1] += cnt[k]; }
-            memcpy(B + o_off, cnt.data(), sizeof(int) * (K + 1));
-            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-            for (int a : p.em) {
-                int q = pos[col_of(arcs[4 * a + 2])]++;
-                B[o_src + q] = arcs[4 * a + 0];
-                B[o_dst + q] = arcs[4 * a + 1];
-                B[o_w + q] = arcs[4 * a + 3];
-                B[o_lcol + q] = col_of(arcs[4 * a + 2]);
-            }
-            for (int k = 0; k < K; ++k) B[o_lab + k] = p.direct ? k : labs[k];
-            I[WF_I_MAXLAB_DEG] = maxdeg;
-        }
-        // ---- final arcs
-        {
-            int o_src = take(p.NF), o_w = take(p.NF), o_arc = take(p.NF);
-            I[WF_I_FIN_SRC] = o_src; I[WF_I_FIN_W] = o_w; I[WF_I_FIN_ARC] = o_arc;
-            for (int i = 0; i < p.NF; ++i) {
-                int a = p.fin[i];
-                B[o_src + i] = arcs[4 * a + 0];
-                B[o_w + i] = arcs[4 * a + 3];
-                B[o_arc + i] = a;
-            }
-        }
-        // ---- beta_T per state and the source state of every original arc
-        {
-            int o_fl = take(S), o_fm = take(S), o_as = take(A + p.NF);
-            I[WF_I_FINB_LOG] = o_fl; I[WF_I_FINB_MAX] = o_fm; I[WF_I_ARC_SRC] = o_as;
-            std::vector<double> m(S, -INFINITY), sum(S, 0.0);
-            for (int a : p.fin) {
-                float w; memcpy(&w, &arcs[4 * a + 3], 4);
-                m[arcs[4 * a]] = std::max(m[arcs[4 * a]], (double)w);
-            }
-            for (int a : p.fin) {
-                float w; memcpy(&w, &arcs[4 * a + 3], 4);
-                sum[arcs[4 * a]] += std::exp((double)w - m[arcs[4 * a]]);
-            }
-            for (int s = 0; s < S; ++s) {
-                float fl = (m[s] == -INFINITY) ? -INFINITY : (float)(m[s] + std::log(sum[s]));
-                float fm = (float)m[s];
-                memcpy(&B[o_fl + s], &fl, 4);
-                memcpy(&B[o_fm + s], &fm, 4);
-            }
-            for (int a = 0; a < A + p.NF; ++a) B[o_as + a] = arcs[4 * a];
-        }
-        // ---- fewest frames any accepted path needs (BFS over emitting arcs from the start state)
-        {
-            std::vector<int> dist(S, -1);
-            std::vector<char> fin_src(S, 0);
-            for (int a : p.fin) fin_src[arcs[4 * a]] = 1;
-            const int32_t* ooff = B + I[WF_I_OUT_OFF];
-            const int32_t* odst = B + I[WF_I_OUT_DST];
-            std::deque<int> q;
-            dist[0] = 0; q.push_back(0);
-            int minlen = INT32_MAX;
-            while (!q.empty()) {
-                int s = q.front(); q.pop_front();
-                if (fin_src[s]) { minlen = dist[s]; break; }   // BFS: the first final-capable state is the nearest
-                for (int e = ooff[s]; e < ooff[s + 1]; ++e)
-                    if (dist[odst[e]] < 0) { dist[odst[e]] = dist[s] + 1; q.push_back(odst[e]); }
-            }
-            I[WF_I_MINLEN] = minlen;
-        }
-        // ---- banded form: Kahn topological order (FIFO, self-loops ignored) of the non-final states
-        {
-            const int Sn = S - 1;   // the super-final state has no emitting arcs
-            I[WF_I_BAND_BW] = -1; I[WF_I_BAND_M] = 0;
-            {
-                int we = 1;
-                for (int a : p.em) { float w; memcpy(&w, &arcs[4 * a + 3], 4); if (w != 0.f) we = 0; }
-                I[WF_I_BAND_WE] = we;
-            }
-            std::vector<int> indeg(Sn, 0), order, pos(Sn, -1);
-            const int32_t* ooff = B + I[WF_I_OUT_OFF];
-            const int32_t* odst = B + I[WF_I_OUT_DST];
-            for (int s = 0; s < Sn; ++s)
-                for (int e = ooff[s]; e < ooff[s + 1]; ++e)
-                    if (odst[e] != s) indeg[odst[e]]++;
-            std::deque<int> q;
-            if (Sn <= 64 * WF_BAND_MAX_R)
-                for (int s = 0; s < Sn; ++s) if (indeg[s] == 0) q.push_back(s);
-            while (!q.empty()) {
-                int s = q.front(); q.pop_front();
-                pos[s] = (int)order.size(); order.push_back(s);
-                for (int e = ooff[s]; e < ooff[s + 1]; ++e)
-                    if (odst[e] != s && --indeg[odst[e]] == 0) q.push_back(odst[e]);
-            }
-            if ((int)order.size() == Sn && Sn >= 1 && Sn <= 64 * WF_BAND_MAX_R) {
-                int bw = 0;
-                for (int a : p.em) bw = std::max(bw, pos[arcs[4 * a + 1]] - pos[arcs[4 * a]]);
-                // arcs per (destination position, distance) cell
-                int m = 0;
-                if (bw <= WF_BAND_MAX_BW) {
-                    std::vector<int> cnt((size_t)Sn * (bw + 1), 0);
-                    for (int a : p.em) m = std::max(m, ++cnt[(size_t)pos[arcs[4 * a + 1]] * (bw + 1) + (pos[arcs[4 * a + 1]] - pos[arcs[4 * a]])]);
-                }
-                if (bw <= WF_BAND_MAX_BW && m <= WF_BAND_MAX_M) {
-                    m = std::max(m, 1);
-                    const size_t cells = (size_t)Sn * (bw + 1) * m;
-                    int o_ord = take(Sn), o_f = take(cells * 2), o_b = take(cells * 2);
-                    I[WF_I_BAND_BW] = bw; I[WF_I_BAND_M] = m; I[WF_I_BAND_ORDER] = o_ord; I[WF_I_BANDF] = o_f; I[WF_I_BANDB] = o_b;
-                    memcpy(B + o_ord, order.data(), sizeof(int) * Sn);
-                    // empty cells: column 0, weight -inf (probability 0)
-                    float ninf = -INFINITY; int32_t nbits; memcpy(&nbits, &ninf, 4);
-                    for (size_t c = 0; c < cells; ++c) { B[o_f + 2 * c] = 0; B[o_f + 2 * c + 1] = nbits; B[o_b + 2 * c] = 0; B[o_b + 2 * c + 1] = nbits; }
-                    std::vector<int> fillf((size_t)Sn * (bw + 1), 0), fillb((size_t)Sn * (bw + 1), 0);
-                    for (int a : p.em) {
-                        const int ps = pos[arcs[4 * a]], pd = pos[arcs[4 * a + 1]], d = pd - ps;
-                        const int col = col_of(arcs[4 * a + 2]);
-                        size_t cf = (size_t)pd * (bw + 1) + d;
-                        size_t ef = cf * m + fillf[cf]++;
-                        B[o_f + 2 * ef] = col; B[o_f + 2 * ef + 1] = arcs[4 * a + 3];
-                        size_t cb = (size_t)(Sn - 1 - ps) * (bw + 1) + d;
-                        size_t eb = cb * m + fillb[cb]++;
-                        B[o_b + 2 * eb] = col; B[o_b + 2 * eb + 1] = arcs[4 * a + 3];
-                    }
-                }
-            }
-        }
-        if (cur > start[g + 1]) return wf_fail(WF_ENOSPC, "internal: blob overflow in fsa %d", g);
+        int maxlab = -1;
+        int rc = prepare_one(gh, g, B, I, cur, limit, &maxlab);
+        if (rc) return rc;
+        gmaxlab = std::max(gmaxlab, maxlab); gmaxS = std::max(gmaxS, (int)I[WF_I_S]); gmaxA = std::max(gmaxA, (int)I[WF_I_A]);
     }
+    B[WF_H_WORDS] = (int32_t)cur;
     B[WF_H_MAX_LABEL] = gmaxlab; B[WF_H_MAX_STATES] = gmaxS; B[WF_H_MAX_ARCS] = gmaxA;
     return WF_OK;
 }
@@ -428,9 +459,32 @@ extern "C" int wf_compose_linear(const int32_t* topo_arcs, const int32_t* topo_a
 // (0 = phone has no state) describe them, and a product state (q != 0, i) gets the arc to phone_state[b[i]]
 // at the place the explicit arc would have in the (phone, token)-sorted arc list of q.
 // ------------------------------------------------------------------------------------------
-extern "C" int wf_topo_index_words(int32_t nA, int32_t nS, int64_t* words) {
-    if (nA < 1 || nS < 2 || !words) return wf_fail(WF_EINVAL, "wf_topo_index_words: bad argument");
-    *words = (int64_t)nS + 1 + 2 * (int64_t)nA;
+// Index layout (int32 words): soff[nS+1] | perm[nA] | key[nA] | f1[nS] | z1[nS] | dense[nS] | maxph | tables...
+//   f1[q] / z1[q]: end of state q's final-arc run / of its phone-0 run inside perm (both start where the previous ends)
+//   dense[q]: 0, or the word offset (from the start of the index) of a table t[0 .. maxph + 1] for a state with more than
+//   kDenseMin phone-labelled arcs: the arcs with phone p are perm[t[p] .. t[p + 1]) -- one load instead of a binary
+//   search over the 5 001 arcs of a BPE-5k hub state in every product state (q, i)
+static const int kDenseMin = 8;
+
+static int topo_max_phone(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA) {
+    int m = 0;
+    for (int a = 0; a < nA; ++a)
+        if (topo_arcs[4 * (size_t)a + 2] >= 0) m = std::max(m, (int)topo_aux[a]);
+    return m;
+}
+
+extern "C" int wf_topo_index_words(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA, int32_t nS, int64_t* words) {
+    if (!topo_arcs || !topo_aux || nA < 1 || nS < 2 || !words) return wf_fail(WF_EINVAL, "wf_topo_index_words: bad argument");
+    std::vector<int> deg(nS, 0);
+    for (int a = 0; a < nA; ++a) {
+        const int s = topo_arcs[4 * (size_t)a];
+        if (s < 0 || s >= nS) return wf_fail(WF_ERANGE, "wf_topo_index_words: topo arc %d state out of range", a);
+        if (topo_arcs[4 * (size_t)a + 2] >= 0 && topo_aux[a] > 0) deg[s]++;
+    }
+    const int64_t maxph = topo_max_phone(topo_arcs, topo_aux, nA);
+    int64_t w = (int64_t)nS + 1 + 2 * (int64_t)nA + 3 * (int64_t)nS + 1;
+    for (int s = 0; s < nS; ++s) if (deg[s] > kDenseMin) w += maxph + 2;
+    *words = w;
     return WF_OK;
 }
 
@@ -440,6 +494,9 @@ extern "C" int wf_topo_index_build(const int32_t* topo_arcs, const int32_t* topo
     int32_t* soff = index;
     int32_t* perm = index + nS + 1;
     int32_t* key = perm + nA;
+    int32_t* f1 = key + nA;
+    int32_t* z1 = f1 + nS;
+    int32_t* dense = z1 + nS;
     std::fill(soff, soff + nS + 1, 0);
     for (int a = 0; a < nA; ++a) {
         const int s = topo_arcs[4 * (size_t)a], d = topo_arcs[4 * (size_t)a + 1];
@@ -454,6 +511,25 @@ extern "C" int wf_topo_index_build(const int32_t* topo_arcs, const int32_t* topo
     for (int s = 0; s < nS; ++s)
         std::stable_sort(perm + soff[s], perm + soff[s + 1], [&](int x, int y) { return ph(x) < ph(y); });
     for (int j = 0; j < nA; ++j) key[j] = ph(perm[j]);
+    const int maxph = topo_max_phone(topo_arcs, topo_aux, nA);
+    dense[nS] = maxph;
+    int64_t w = (int64_t)nS + 1 + 2 * (int64_t)nA + 3 * (int64_t)nS + 1;
+    for (int s = 0; s < nS; ++s) {
+        const int32_t* ke = key + soff[s + 1];
+        f1[s] = (int32_t)(std::upper_bound((const int32_t*)key + soff[s], ke, -1) - key);
+        z1[s] = (int32_t)(std::upper_bound((const int32_t*)key + f1[s], ke, 0) - key);
+        dense[s] = 0;
+        if (soff[s + 1] - z1[s] > kDenseMin) {
+            dense[s] = (int32_t)w;
+            int32_t* t = index + w;
+            w += maxph + 2;
+            int j = z1[s];
+            for (int p = 0; p <= maxph + 1; ++p) {   // t[p] = first position with key >= p (t[0] = t[1] = z1: phone 0 is not in this run)
+                while (j < soff[s + 1] && key[j] < p) ++j;
+                t[p] = j;
+            }
+        }
+    }
     return WF_OK;
 }
 
@@ -493,6 +569,128 @@ struct PairMap {
 };
 }  // namespace
 
+namespace {
+struct TopoView {
+    const int32_t* arcs; const int32_t* aux; int nA, nS;
+    const int32_t* index; int ctc_cross; const int32_t* phone_state; const int32_t* phone_token; int num_phones;
+};
+struct ComposeScratch {
+    PairMap id;
+    std::vector<int64_t> order;
+    std::vector<int32_t> arcs, aux;   // the composed graph of the last utterance: arcs [n][4] (final arcs: dst = -1), aux [n]
+    int num_states = 0;
+};
+
+// compose(topo, linear transcript seq[0..L)) into X.arcs / X.aux (state ids in BFS order, super-final = X.num_states - 1)
+int compose_linear_one(const TopoView& tv, const int32_t* seq, int L, int b, ComposeScratch& X) {
+    const int nA = tv.nA, nS = tv.nS;
+    const int32_t* topo_arcs = tv.arcs;
+    const int32_t* index = tv.index;
+    const int32_t* soff = index;
+    const int32_t* perm = index + nS + 1;
+    const int32_t* key = perm + nA;
+    const int32_t* f1s = key + nA;
+    const int32_t* z1s = f1s + nS;
+    const int32_t* dense = z1s + nS;
+    const int maxph = dense[nS];
+    const int ctc_cross = tv.ctc_cross;
+    const int32_t* phone_state = tv.phone_state;
+    const int32_t* phone_token = tv.phone_token;
+    PairMap& id = X.id;
+    std::vector<int64_t>& order = X.order;
+    std::vector<int32_t>& arcs = X.arcs;
+    std::vector<int32_t>& aux = X.aux;
+    for (int i = 0; i < L; ++i)
+        if (seq[i] < 1 || (ctc_cross && seq[i] >= tv.num_phones))
+            return wf_fail(WF_ERANGE, "wf_compose_linear_batch: transcript %d position %d: phone %d out of range", b, i, seq[i]);
+    id.reset(8 * (size_t)(L + 2));
+    order.clear(); arcs.clear(); aux.clear();
+    auto pkey = [&](int q, int i) { return (int64_t)q * (L + 1) + i; };
+    bool ins;
+    id.get(pkey(0, 0), 0, &ins);
+    order.push_back(pkey(0, 0));
+    auto emit = [&](int head, int q2, int ni, int tok, int32_t wbits, int phv) {
+        if (order.size() * 2 > id.k.size()) id.grow();
+        const int32_t nid = id.get(pkey(q2, ni), (int32_t)order.size(), &ins);
+        if (ins) order.push_back(pkey(q2, ni));
+        arcs.push_back(head); arcs.push_back(nid); arcs.push_back(tok); arcs.push_back(wbits);
+        aux.push_back(phv);
+    };
+    for (size_t head = 0; head < order.size(); ++head) {
+        const int q = (int)(order[head] / (L + 1)), i = (int)(order[head] % (L + 1));
+        const int lo = soff[q], hi = soff[q + 1];
+        // runs of this state's arcs: final (key -1), phone 0, phone b[i]
+        const int f1 = f1s[q], z1 = z1s[q];
+        int p0 = hi, p1 = hi, nph = 0;
+        if (i < L) {
+            nph = seq[i];
+            if (dense[q]) {
+                if (nph <= maxph) { const int32_t* t = index + dense[q]; p0 = t[nph]; p1 = t[nph + 1]; }
+            } else {
+                p0 = z1;
+                while (p0 < hi && key[p0] < nph) ++p0;
+                p1 = p0;
+                while (p1 < hi && key[p1] == nph) ++p1;
+            }
+        }
+        // implicit CTC arc (q -> phone_state[b[i]], b[i] : b[i])
+        int cq = 0, ctok = 0;
+        const bool cross = ctc_cross && q != 0 && i < L && phone_state[nph] > 0 && phone_state[nph] != q;
+        if (cross) { cq = phone_state[nph]; ctok = phone_token[nph]; }
+        int x = f1, y = p0;
+        if (!cross) {
+            // emitting arcs in topology order: merge the phone-0 run and the phone-b[i] run by arc id
+            while (x < z1 || y < p1) {
+                const int ax = x < z1 ? perm[x] : INT32_MAX, ay = y < p1 ? perm[y] : INT32_MAX;
+                if (ax < ay) {
+                    const int32_t* r = topo_arcs + 4 * (size_t)ax;
+                    emit((int)head, r[1], i, r[2], r[3], 0);
+                    ++x;
+                } else {
+                    const int32_t* r = topo_arcs + 4 * (size_t)ay;
+                    emit((int)head, r[1], i + 1, r[2], r[3], nph);
+                    ++y;
+                }
+            }
+        } else {
+            // the factored CTC topology is sorted by (phone, token) per state (prepare_ctc.sh: fstarcsort olabel):
+            // phone-0 arcs first, then the phone-b[i] arcs by token, the implicit one among them
+            for (; x < z1; ++x) {
+                const int32_t* r = topo_arcs + 4 * (size_t)perm[x];
+                emit((int)head, r[1], i, r[2], r[3], 0);
+            }
+            bool done = false;
+            for (; y < p1; ++y) {
+                const int32_t* r = topo_arcs + 4 * (size_t)perm[y];
+                if (!done && r[2] > ctok) { emit((int)head, cq, i + 1, ctok, 0, nph); done = true; }
+                emit((int)head, r[1], i + 1, r[2], r[3], nph);
+            }
+            if (!done) emit((int)head, cq, i + 1, ctok, 0, nph);
+        }
+        // final arcs of q at the last position: after the emitting arcs of this product state
+        if (i == L)
+            for (int j = lo; j < f1; ++j) {
+                const int32_t* r = topo_arcs + 4 * (size_t)perm[j];
+                arcs.push_back((int32_t)head); arcs.push_back(-1); arcs.push_back(-1); arcs.push_back(r[3]);
+                aux.push_back(-1);
+            }
+    }
+    X.num_states = (int)order.size() + 1;
+    return WF_OK;
+}
+
+// copies X's graph to its place in the FsaVec arrays (final arcs get their destination)
+void compose_store(const ComposeScratch& X, int32_t* out_arcs, int32_t* out_aux) {
+    const int64_t n = (int64_t)X.aux.size();
+    const int sf = X.num_states - 1;
+    for (int64_t a = 0; a < n; ++a) {
+        int32_t* o = out_arcs + 4 * (size_t)a;
+        o[0] = X.arcs[4 * a]; o[1] = X.arcs[4 * a + 1] < 0 ? sf : X.arcs[4 * a + 1]; o[2] = X.arcs[4 * a + 2]; o[3] = X.arcs[4 * a + 3];
+        out_aux[a] = X.aux[a];
+    }
+}
+}  // namespace
+
 extern "C" int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA, int32_t nS,
                                        const int32_t* index, int32_t ctc_cross, const int32_t* phone_state,
                                        const int32_t* phone_token, int32_t num_phones,
@@ -503,108 +701,192 @@ extern "C" int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* 
         return wf_fail(WF_EINVAL, "wf_compose_linear_batch: bad argument");
     if (ctc_cross && (!phone_state || !phone_token || num_phones < 1))
         return wf_fail(WF_EINVAL, "wf_compose_linear_batch: ctc_cross needs the phone -> state / token tables");
-    const int32_t* soff = index;
-    const int32_t* perm = index + nS + 1;
-    const int32_t* key = perm + nA;
-    PairMap id;
-    std::vector<int64_t> order;
-    std::vector<int32_t> arcs, aux;
+    const TopoView tv{topo_arcs, topo_aux, nA, nS, index, ctc_cross, phone_state, phone_token, num_phones};
+    static thread_local ComposeScratch X;
     int64_t w = 0;
     bool fits = out_arcs && out_aux;
     out_arc_off[0] = 0;
     for (int b = 0; b < B; ++b) {
-        const int32_t* seq = phones + phones_off[b];
         const int L = phones_off[b + 1] - phones_off[b];
         if (L < 0 || (L > 0 && !phones)) return wf_fail(WF_EINVAL, "wf_compose_linear_batch: transcript %d", b);
-        for (int i = 0; i < L; ++i)
-            if (seq[i] < 1 || (ctc_cross && seq[i] >= num_phones))
-                return wf_fail(WF_ERANGE, "wf_compose_linear_batch: transcript %d position %d: phone %d out of range", b, i, seq[i]);
-        id.reset(8 * (size_t)(L + 2));
-        order.clear(); arcs.clear(); aux.clear();
-        auto pkey = [&](int q, int i) { return (int64_t)q * (L + 1) + i; };
-        bool ins;
-        id.get(pkey(0, 0), 0, &ins);
-        order.push_back(pkey(0, 0));
-        auto emit = [&](int head, int q2, int ni, int tok, int32_t wbits, int phv) {
-            if (order.size() * 2 > id.k.size()) id.grow();
-            const int32_t nid = id.get(pkey(q2, ni), (int32_t)order.size(), &ins);
-            if (ins) order.push_back(pkey(q2, ni));
-            arcs.push_back(head); arcs.push_back(nid); arcs.push_back(tok); arcs.push_back(wbits);
-            aux.push_back(phv);
-        };
-        for (size_t head = 0; head < order.size(); ++head) {
-            const int q = (int)(order[head] / (L + 1)), i = (int)(order[head] % (L + 1));
-            const int lo = soff[q], hi = soff[q + 1];
-            // runs of this state's arcs: final (key -1), phone 0, phone b[i]
-            const int32_t* kb = key + lo;
-            const int32_t* ke = key + hi;
-            const int f1 = (int)(std::upper_bound(kb, ke, -1) - key);
-            const int z1 = (int)(std::upper_bound(key + f1, ke, 0) - key);
-            int p0 = hi, p1 = hi, nph = 0;
-            if (i < L) {
-                nph = seq[i];
-                p0 = (int)(std::lower_bound(key + z1, ke, nph) - key);
-                p1 = (int)(std::upper_bound(key + p0, ke, nph) - key);
-            }
-            // implicit CTC arc (q -> phone_state[b[i]], b[i] : b[i])
-            int cq = 0, ctok = 0;
-            const bool cross = ctc_cross && q != 0 && i < L && phone_state[nph] > 0 && phone_state[nph] != q;
-            if (cross) { cq = phone_state[nph]; ctok = phone_token[nph]; }
-            int x = f1, y = p0;
-            if (!cross) {
-                // emitting arcs in topology order: merge the phone-0 run and the phone-b[i] run by arc id
-                while (x < z1 || y < p1) {
-                    const int ax = x < z1 ? perm[x] : INT32_MAX, ay = y < p1 ? perm[y] : INT32_MAX;
-                    if (ax < ay) {
-                        const int32_t* r = topo_arcs + 4 * (size_t)ax;
-                        emit((int)head, r[1], i, r[2], r[3], 0);
-                        ++x;
-                    } else {
-                        const int32_t* r = topo_arcs + 4 * (size_t)ay;
-                        emit((int)head, r[1], i + 1, r[2], r[3], nph);
-                        ++y;
-                    }
-                }
-            } else {
-                // the factored CTC topology is sorted by (phone, token) per state (prepare_ctc.sh: fstarcsort olabel):
-                // phone-0 arcs first, then the phone-b[i] arcs by token, the implicit one among them
-                for (; x < z1; ++x) {
-                    const int32_t* r = topo_arcs + 4 * (size_t)perm[x];
-                    emit((int)head, r[1], i, r[2], r[3], 0);
-                }
-                bool done = false;
-                for (; y < p1; ++y) {
-                    const int32_t* r = topo_arcs + 4 * (size_t)perm[y];
-                    if (!done && r[2] > ctok) { emit((int)head, cq, i + 1, ctok, 0, nph); done = true; }
-                    emit((int)head, r[1], i + 1, r[2], r[3], nph);
-                }
-                if (!done) emit((int)head, cq, i + 1, ctok, 0, nph);
-            }
-            // final arcs of q at the last position: after the emitting arcs of this product state
-            if (i == L)
-                for (int j = lo; j < f1; ++j) {
-                    const int32_t* r = topo_arcs + 4 * (size_t)perm[j];
-                    arcs.push_back((int32_t)head); arcs.push_back(-1); arcs.push_back(-1); arcs.push_back(r[3]);
-                    aux.push_back(-1);
-                }
-        }
-        const int sf = (int)order.size();
-        const int64_t n = (int64_t)aux.size();
+        int rc = compose_linear_one(tv, phones + phones_off[b], L, b, X);
+        if (rc) return rc;
+        const int64_t n = (int64_t)X.aux.size();
         if (w + n > INT32_MAX) return wf_fail(WF_EUNSUPPORTED, "wf_compose_linear_batch: more than 2^31 arcs");
-        if (fits && w + n <= cap) {
-            for (int64_t a = 0; a < n; ++a) {
-                int32_t* o = out_arcs + 4 * (size_t)(w + a);
-                o[0] = arcs[4 * a]; o[1] = arcs[4 * a + 1] < 0 ? sf : arcs[4 * a + 1]; o[2] = arcs[4 * a + 2]; o[3] = arcs[4 * a + 3];
-                out_aux[w + a] = aux[a];
-            }
-        } else {
-            fits = false;
-        }
+        if (fits && w + n <= cap) compose_store(X, out_arcs + 4 * (size_t)w, out_aux + w);
+        else fits = false;
         w += n;
         out_arc_off[b + 1] = (int32_t)w;
-        out_num_states[b] = sf + 1;
+        out_num_states[b] = X.num_states;
     }
     if (!fits) return wf_fail(WF_ENOSPC, "wf_compose_linear_batch: arc capacity %lld < %lld", (long long)cap, (long long)w);
+    return WF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host worker pool: the numerator compiler's utterances are independent, so a batch is split over a few persistent
+// threads (created on first use, parked on a condition variable in between).  One parallel region at a time; a caller
+// that finds the pool busy runs its region alone on its own thread.
+// ------------------------------------------------------------------------------------------
+namespace {
+class WorkerPool {
+  public:
+    static WorkerPool& get() { static WorkerPool p; return p; }
+    // runs fn(worker, nworkers) on `want` workers (the caller is worker 0) and waits for all of them
+    void run(int want, const std::function<void(int, int)>& fn) {
+        want = std::max(1, std::min(want, kMax));
+        std::unique_lock<std::mutex> own(region_, std::try_to_lock);
+        if (want == 1 || !own.owns_lock()) { fn(0, 1); return; }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            while ((int)threads_.size() < want - 1) {
+                const int id = (int)threads_.size() + 1;
+                threads_.emplace_back([this, id] { loop(id); });
+            }
+            fn_ = &fn; n_ = want; pending_ = want - 1; ++gen_;
+        }
+        cv_.notify_all();
+        fn(0, want);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+  private:
+    static constexpr int kMax = 16;
+    void loop(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int, int)>* fn = nullptr;
+            int n = 0;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                if (id < n_) { fn = fn_; n = n_; }
+            }
+            if (fn) {
+                (*fn)(id, n);
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex m_, region_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int, int)>* fn_ = nullptr;
+    int n_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// wf_numerator_compile: wf_compose_linear_batch + wf_graph_prepare in one call, the utterances spread over
+// `nthreads` host threads.  What a training step needs between the data loader and the loss call
+// (models.py:263-270 / datapipe.py:233-256 run on every step).  Results are identical to the two calls in sequence,
+// except that the blob keeps every graph at the start of its upper-bound region (gaps between graphs; B[WF_H_WORDS]
+// = the whole extent), so that the threads never wait for each other's sizes.
+// Two-call protocol as for wf_compose_linear_batch: too small an arc capacity or blob returns WF_ENOSPC with the sizes
+// needed in out_arc_off[B] and *blob_bytes_needed.
+// ------------------------------------------------------------------------------------------
+extern "C" int wf_numerator_compile(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA, int32_t nS,
+                                    const int32_t* index, int32_t ctc_cross, const int32_t* phone_state,
+                                    const int32_t* phone_token, int32_t num_phones,
+                                    const int32_t* phones, const int32_t* phones_off, int32_t B,
+                                    int32_t* out_arcs, int32_t* out_aux, int64_t cap, int32_t* out_arc_off,
+                                    int32_t* out_num_states, void* blob, size_t blob_bytes, size_t* blob_bytes_needed,
+                                    int32_t nthreads) {
+    if (!topo_arcs || !topo_aux || !index || nA < 1 || nS < 2 || B < 1 || !phones_off || !out_arc_off || !out_num_states ||
+        !out_arcs || !out_aux || !blob || !blob_bytes_needed)
+        return wf_fail(WF_EINVAL, "wf_numerator_compile: bad argument");
+    if (ctc_cross && (!phone_state || !phone_token || num_phones < 1))
+        return wf_fail(WF_EINVAL, "wf_numerator_compile: ctc_cross needs the phone -> state / token tables");
+    for (int b = 0; b < B; ++b)
+        if (phones_off[b + 1] < phones_off[b] || (phones_off[b + 1] > phones_off[b] && !phones))
+            return wf_fail(WF_EINVAL, "wf_numerator_compile: transcript %d", b);
+    const TopoView tv{topo_arcs, topo_aux, nA, nS, index, ctc_cross, phone_state, phone_token, num_phones};
+    const int nw = std::max(1, std::min<int>(std::min<int>(nthreads, B), 16));
+    // phase 1: every worker composes its (contiguous) share into its own buffers
+    struct Share { std::vector<int32_t> arcs, aux, narcs, nstates; int rc = 0; char err[512] = ""; };
+    std::vector<Share> shares(nw);
+    auto range = [&](int w, int n, int* lo, int* hi) { *lo = (int)((int64_t)B * w / n); *hi = (int)((int64_t)B * (w + 1) / n); };
+    WorkerPool::get().run(nw, [&](int w, int n) {
+        // (a region that found the pool busy runs with n = 1: worker 0 then takes every share)
+        for (int sh = w; sh < nw; sh += n) {
+            Share& S = shares[sh];
+            int lo, hi;
+            range(sh, nw, &lo, &hi);
+            static thread_local ComposeScratch X;
+            for (int b = lo; b < hi && !S.rc; ++b) {
+                S.rc = compose_linear_one(tv, phones + phones_off[b], phones_off[b + 1] - phones_off[b], b, X);
+                if (S.rc) { snprintf(S.err, sizeof(S.err), "%s", wf_last_error()); break; }
+                const size_t at = S.aux.size();
+                S.arcs.resize(4 * (at + X.aux.size()));
+                S.aux.resize(at + X.aux.size());
+                compose_store(X, S.arcs.data() + 4 * at, S.aux.data() + at);
+                S.narcs.push_back((int32_t)X.aux.size());
+                S.nstates.push_back(X.num_states);
+            }
+        }
+    });
+    for (auto& S : shares) if (S.rc) return wf_fail(S.rc, "%s", S.err);
+    // sizes: arc offsets, blob regions (upper bound per graph)
+    int64_t w = 0;
+    out_arc_off[0] = 0;
+    std::vector<size_t> start(B + 1);
+    start[0] = pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * B);
+    for (int sh = 0, b = 0; sh < nw; ++sh)
+        for (size_t j = 0; j < shares[sh].narcs.size(); ++j, ++b) {
+            w += shares[sh].narcs[j];
+            if (w > INT32_MAX) return wf_fail(WF_EUNSUPPORTED, "wf_numerator_compile: more than 2^31 arcs");
+            out_arc_off[b + 1] = (int32_t)w;
+            out_num_states[b] = shares[sh].nstates[j];
+            start[b + 1] = start[b] + fsa_words_bound((size_t)shares[sh].nstates[j], (size_t)shares[sh].narcs[j]);
+        }
+    *blob_bytes_needed = start[B] * 4;
+    if (start[B] >= (size_t)1 << 31) return wf_fail(WF_EUNSUPPORTED, "prepared graph exceeds 2^31 words");
+    if (w > cap || start[B] * 4 > blob_bytes)
+        return wf_fail(WF_ENOSPC, "wf_numerator_compile: needs %lld arcs (capacity %lld) and a %zu B blob (%zu B given)", (long long)w,
+                       (long long)cap, start[B] * 4, blob_bytes);
+    // phase 2: arcs to their place, then each graph's tables
+    int32_t* Bw = (int32_t*)blob;
+    wf_graph_host gh{B, out_arcs, out_arc_off, out_num_states};
+    std::vector<int> maxlab(B, -1), rcs(nw, 0);
+    std::vector<std::string> errs(nw);
+    WorkerPool::get().run(nw, [&](int wk, int n) {
+        for (int sh = wk; sh < nw; sh += n) {
+            int lo, hi;
+            range(sh, nw, &lo, &hi);
+            const Share& S = shares[sh];
+            if (hi > lo) {
+                memcpy(out_arcs + 4 * (size_t)out_arc_off[lo], S.arcs.data(), sizeof(int32_t) * S.arcs.size());
+                memcpy(out_aux + out_arc_off[lo], S.aux.data(), sizeof(int32_t) * S.aux.size());
+            }
+            for (int b = lo; b < hi && !rcs[sh]; ++b) {
+                size_t cur = start[b];
+                rcs[sh] = prepare_one(&gh, b, Bw, Bw + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * b, cur, start[b + 1], &maxlab[b]);
+                if (rcs[sh]) errs[sh] = wf_last_error();
+            }
+        }
+    });
+    for (int sh = 0; sh < nw; ++sh) if (rcs[sh]) return wf_fail(rcs[sh], "%s", errs[sh].c_str());
+    memset(Bw, 0, sizeof(int32_t) * WF_HDR_WORDS);
+    Bw[WF_H_MAGIC] = WF_BLOB_MAGIC;
+    Bw[WF_H_NUM_FSAS] = B;
+    Bw[WF_H_WORDS] = (int32_t)start[B];
+    int gmaxlab = -1, gmaxS = 0, gmaxA = 0;
+    for (int b = 0; b < B; ++b) {
+        const int32_t* I = Bw + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * b;
+        gmaxlab = std::max(gmaxlab, maxlab[b]); gmaxS = std::max(gmaxS, (int)I[WF_I_S]); gmaxA = std::max(gmaxA, (int)I[WF_I_A]);
+    }
+    Bw[WF_H_MAX_LABEL] = gmaxlab; Bw[WF_H_MAX_STATES] = gmaxS; Bw[WF_H_MAX_ARCS] = gmaxA;
     return WF_OK;
 }
 

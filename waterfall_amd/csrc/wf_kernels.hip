@@ -4298,6 +4298,79 @@ extern "C" int wf_loss_stats(const float* tot, int32_t B, float n_frames, float*
     return WF_OK;
 }
 
+// ---- the drop-in's eager gradient (waterfall_amd/graph.py): loss reduction and upstream-gradient scaling ----------
+// loss_reduce_kernel: out[0] = sum_b w[b] * (-tot[b]) (w == NULL: 1), one workgroup.  graph.py:66-76's reductions
+// ('sum'; 'mean' with w[b] = 1 / (B * target_lengths[b])) without three elementwise torch launches.
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const float* tot, const float* w, int B, float* out) {
+    __shared__ float rs[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) s -= tot[i] * (w ? w[i] : 1.f);   // -(-inf) = +inf: an infeasible utterance
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) rs[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+}
+
+extern "C" int wf_loss_reduce(const float* tot, const float* w, int32_t B, float* out, void* stream) {
+    if (!tot || !out || B < 0) return wf_fail(WF_EINVAL, "wf_loss_reduce: bad argument");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tot, w, B, out);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+// grad_scale_kernel: grad[seq, t, label_k] *= g for the label columns of the utterance's (compact) graph, g = gs[u]
+// (per_utt) or gs[0]; a wavefront whose factor is exactly 1 exits at once -- the usual loss.backward().
+struct GradScaleArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const int32_t* seq2utt;
+    const float* gs;
+    int per_utt;
+    float* grad;
+    int64_t strideB, strideT;
+    int Tmax;
+};
+
+__global__ void __launch_bounds__(64) grad_scale_kernel(GradScaleArgs p) {
+    const int lane = threadIdx.x;
+    const int f0 = blockIdx.x * kPostFR, q = blockIdx.y;
+    const int u = p.seq2utt[q];
+    if (u < 0) return;
+    const float g = p.gs[p.per_utt ? u : 0];
+    if (g == 1.f) return;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int start = (int)U[WF_U_START], T = (int)U[WF_U_T], K = (int)U[WF_U_K], direct = (int)U[WF_U_DIRECT];
+    const int32_t* labels = p.blob + U[WF_U_LABELS];
+    const int t0 = max(f0 - start, 0), t1 = min(f0 + kPostFR - start, T);
+    for (int k = lane; k < K; k += 64) {
+        const int c = direct ? k : labels[k];
+        for (int t = t0; t < t1; ++t) {
+            float* e = p.grad + (int64_t)q * p.strideB + (int64_t)(start + t) * p.strideT + c;
+            const float v = *e;
+            if (v != 0.f) *e = v * g;
+        }
+    }
+}
+
+// Must follow a wf_fb_logsum(grad != NULL) call with the same graph / seg / workspace on the same stream (its tables
+// are still in the workspace).  gs: DEVICE fp32, [B] (per_utt != 0) or [1].
+extern "C" int wf_grad_scale(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const int32_t* seg,
+                             int32_t B, int32_t num_seqs, int32_t Tmax, int32_t V, int64_t strideB, int64_t strideT,
+                             const float* gs, int32_t per_utt, float* grad, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    if (!graph_dev || !seg || !gs || !grad || !workspace) return wf_fail(WF_EINVAL, "wf_grad_scale: null pointer");
+    Plan P;
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P);
+    if (rc) return rc;
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
+    GradScaleArgs a{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), (const int32_t*)(ws + P.off_seq2utt), gs, per_utt ? 1 : 0,
+                    grad, strideB, strideT, Tmax};
+    hipLaunchKernelGGL(grad_scale_kernel, dim3((Tmax + kPostFR - 1) / kPostFR, num_seqs), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
 extern "C" int wf_timing_enable(int on) { g_tm.on = on != 0; g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = false; return WF_OK; }
 
 // ms[0..4] = gather, sweep, post, zero-fill, check + fallback kernel time of the last timed call(s);

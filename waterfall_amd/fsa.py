@@ -36,6 +36,7 @@ class Fsa:
         self.utt2fsa = None if utt2fsa is None else np.ascontiguousarray(utt2fsa, dtype=np.int32)
         self.device = torch.device("cpu")
         self._blob_host = None
+        self._blob_pin = None     # pinned torch tensor behind _blob_host (numerator compiler): asynchronous upload
         self._blob_dev = {}
 
     # ---- construction -----------------------------------------------------------------------
@@ -147,17 +148,48 @@ class Fsa:
             lib = _lib.lib()
             gh = self._graph_host_struct()
             n = C.c_size_t(0)
-            _lib.check(lib.wf_graph_prepare_bytes(C.byref(gh), C.byref(n)))
-            blob = np.zeros(n.value // 4, dtype=np.int32)
+            _lib.check(lib.wf_graph_prepare_bytes(C.byref(gh), C.byref(n)))      # an upper bound, O(1) per graph
+            blob = np.empty(n.value // 4, dtype=np.int32)
             _lib.check(lib.wf_graph_prepare(C.byref(gh), blob.ctypes.data, n.value))
-            self._blob_host = blob
+            self._blob_host = blob[:int(blob[2])].copy()                          # WF_H_WORDS: what was used
         return self._blob_host
+
+    def all_compact(self):
+        """True when every FSA uses compact label columns (a numerator: few distinct labels out of a large table), i.e.
+        the gradient w.r.t. log_probs has only K non-zeros per row."""
+        v = getattr(self, "_all_compact", None)
+        if v is None:
+            from .csrc_layout import HDR_WORDS, INFO_WORDS, INFO
+            b = self.blob_host()
+            v = self._all_compact = bool((b[HDR_WORDS + INFO["DIRECT"]:HDR_WORDS + INFO_WORDS * self.num_fsas:INFO_WORDS] == 0).all())
+        return v
+
+    def workspace_bytes(self, seg, num_seqs, V, flags, need_grad):
+        """wf_fb_workspace_bytes, cached per (segments, N, V, flags): a training loop asks with the same values twice per
+        step (numerator graphs are new objects every step; a denominator topology is asked thousands of times)."""
+        key = (seg.tobytes(), num_seqs, V, flags, bool(need_grad))
+        c = self.__dict__.setdefault("_ws_cache", {})
+        n = c.get(key)
+        if n is None:
+            if len(c) > 64:
+                c.clear()
+            out = C.c_size_t(0)
+            _lib.check(_lib.lib().wf_fb_workspace_bytes(self.blob_host().ctypes.data, None if self.utt2fsa is None else self.utt2fsa.ctypes.data,
+                                                         seg.ctypes.data, seg.shape[0], num_seqs, V, flags, 1 if need_grad else 0, C.byref(out)))
+            n = c[key] = out.value
+        return n
 
     def blob_dev(self, device):
         device = torch.device(device)
         key = str(device)
         if key not in self._blob_dev:
-            self._blob_dev[key] = torch.from_numpy(self.blob_host()).to(device)
+            host = self.blob_host()
+            if self._blob_pin is not None:
+                dev = torch.empty(host.size, dtype=torch.int32, device=device)
+                dev.copy_(self._blob_pin[:host.size], non_blocking=True)      # stream-ordered, no host wait
+                self._blob_dev[key] = dev
+            else:
+                self._blob_dev[key] = torch.from_numpy(host).to(device)
         return self._blob_dev[key]
 
     def to(self, device):

@@ -103,6 +103,88 @@ class _FbFunction(torch.autograd.Function):
         return grad, None, None, None, None
 
 
+class _EagerLossFunction(torch.autograd.Function):
+    """The whole of graph.py:61-76 as ONE autograd node: loss = reduction(-tot), computed by the FUSED wf_fb_logsum call
+    (loss and d loss / d log_probs in one pass: no second C call, no separate row check), with the reduction's own factor
+    -w_b folded into the gradient.  backward only multiplies the kept gradient by the upstream gradient
+    (wf_grad_scale: nothing to do when that is 1, the usual loss.backward()).  Used for graphs with compact label
+    columns (numerators: the gradient is K non-zeros per row); the others take _FbFunction."""
+
+    @staticmethod
+    def forward(ctx, log_probs, graph, dense, reduction, weights):
+        lp, seg, B = _check_inputs(graph, dense)
+        lib = _lib.lib()
+        dev = lp.device
+        N, T, V = lp.shape
+        gh, gd = graph.blob_host(), graph.blob_dev(dev)
+        nbytes = graph.workspace_bytes(seg, N, V, 0, True)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        tot = torch.empty(B, dtype=torch.float32, device=dev)
+        grad = torch.empty_strided(lp.shape, lp.stride(), dtype=torch.float32, device=dev)
+        gscale = weights if weights is not None else _const(dev, B, -1.0)      # d loss / d tot_b
+        st = _stream(dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.wf_fb_logsum(_np_ptr(gh), _ptr(gd), _np_ptr(graph.utt2fsa), _ptr(lp), lp.stride(0), lp.stride(1),
+                                        N, T, V, _np_ptr(seg), B, 0.0, 0, _ptr(gscale), _ptr(tot), _ptr(grad), _ptr(ws),
+                                        nbytes, st))
+            if reduction == 'none':
+                loss = tot.neg()
+            else:
+                loss = torch.empty((), dtype=torch.float32, device=dev)
+                # 'mean': weights = -1 / (B * target_lengths) -> w = -weights
+                w = None if weights is None else weights.neg()
+                _lib.check(lib.wf_loss_reduce(_ptr(tot), _ptr(w), B, _ptr(loss), st))
+        ctx.graph, ctx.dense, ctx.ws, ctx.ws_bytes, ctx.grad, ctx.per_utt = graph, dense, ws, nbytes, grad, reduction == 'none'
+        ctx.shape = (N, T, V)
+        ctx.strides = (lp.stride(0), lp.stride(1))
+        ctx.gscale = gscale
+        ctx.save_for_backward(lp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        grad, ctx.grad = ctx.grad, None
+        graph, dense = ctx.graph, ctx.dense
+        seg = dense.supervision_segments.numpy()
+        N, T, V = ctx.shape
+        (lp,) = ctx.saved_tensors
+        dev = lp.device
+        gs = gout.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            if grad is None:   # a second backward through a retained graph: the kept gradient was handed out, compute it again
+                grad = torch.empty_strided(lp.shape, lp.stride(), dtype=torch.float32, device=dev)
+                tot = torch.empty(seg.shape[0], dtype=torch.float32, device=dev)
+                _lib.check(_lib.lib().wf_fb_logsum(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
+                                                   _ptr(lp), lp.stride(0), lp.stride(1), N, T, V, _np_ptr(seg), seg.shape[0], 0.0, 0,
+                                                   _ptr(ctx.gscale), _ptr(tot), _ptr(grad), _ptr(ctx.ws), ctx.ws_bytes, _stream(dev)))
+            _lib.check(_lib.lib().wf_grad_scale(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
+                                                _np_ptr(seg), seg.shape[0], N, T, V, ctx.strides[0], ctx.strides[1], _ptr(gs),
+                                                1 if ctx.per_utt else 0, _ptr(grad), _ptr(ctx.ws), ctx.ws_bytes, _stream(dev)))
+        return grad, None, None, None, None
+
+
+_CONST = {}
+
+
+def _const(dev, n, value):
+    key = (str(dev), n, value)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((n,), value, dtype=torch.float32, device=dev)
+    return t
+
+
+_EAGER = True
+
+
+def set_eager_gradient(on: bool):
+    """True (default): graphloss() on graphs with compact label columns computes loss AND gradient in its forward (the
+    fused call) and keeps the gradient for backward -- one backward per forward.  False: the two-call split
+    (forward: sweeps + row check; backward: posteriors), which supports retain_graph / double backward passes."""
+    global _EAGER
+    _EAGER = bool(on)
+
+
 _BEAM_MODE = "exact"
 
 
@@ -140,26 +222,40 @@ class GraphLoss(nn.Module):
     def forward(self, decoding_graph: Fsa, dense_fsa_vec: DenseFsaVec, target_lengths: torch.Tensor = None,
                 max_states: int = 15000000, max_arcs: int = 549755813888) -> torch.Tensor:
         # max_states / max_arcs are accepted and ignored, exactly as in the reference (graph.py:42-43,61-62)
-        tot_scores = _FbFunction.apply(dense_fsa_vec.log_probs, decoding_graph, dense_fsa_vec,
-                                       _beam_value(self.output_beam), self.use_double_scores)
-        loss = -1 * tot_scores
-        loss = loss.to(torch.float32)
-        if self.reduction == 'none':
-            return loss
-        elif self.reduction == 'sum':
-            return loss.sum()
-        else:
-            assert self.reduction == 'mean'
-            loss = loss / target_lengths.to(loss.device)
-            return loss.mean()
+        return _graphloss(decoding_graph, dense_fsa_vec, self.output_beam, self.reduction, self.use_double_scores,
+                          target_lengths)
+
+
+def _graphloss(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double_scores, target_lengths):
+    """graph.py:61-76: loss = -tot_scores (float32), reduced 'none' | 'sum' | 'mean' (/ target_lengths, then batch mean)."""
+    beam = _beam_value(output_beam)
+    lp = dense_fsa_vec.log_probs
+    if (_EAGER and beam == 0.0 and not use_double_scores and lp.requires_grad and torch.is_grad_enabled()
+            and isinstance(decoding_graph, Fsa) and decoding_graph.all_compact()):
+        weights = None
+        if reduction == 'mean':
+            B = dense_fsa_vec.supervision_segments.shape[0]
+            weights = (-1.0 / B) / target_lengths.to(device=lp.device, dtype=torch.float32)
+        return _EagerLossFunction.apply(lp, decoding_graph, dense_fsa_vec, reduction, weights)
+    tot_scores = _FbFunction.apply(lp, decoding_graph, dense_fsa_vec, beam, use_double_scores)
+    loss = -1 * tot_scores
+    loss = loss.to(torch.float32)
+    if reduction == 'none':
+        return loss
+    elif reduction == 'sum':
+        return loss.sum()
+    else:
+        assert reduction == 'mean'
+        loss = loss / target_lengths.to(loss.device)
+        return loss.mean()
 
 
 def graphloss(decoding_graph: Fsa, dense_fsa_vec: DenseFsaVec, output_beam: float = 10, reduction: str = 'sum',
               use_double_scores: bool = False, max_states: int = 15000000,
               target_lengths: torch.Tensor = None) -> torch.Tensor:
     """graph.py:79-118."""
-    m = GraphLoss(output_beam=output_beam, reduction=reduction, use_double_scores=use_double_scores)
-    return m(decoding_graph, dense_fsa_vec, target_lengths, max_states=max_states)
+    assert reduction in ('none', 'mean', 'sum')
+    return _graphloss(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double_scores, target_lengths)
 
 
 def tot_scores(graph: Fsa, dense: DenseFsaVec, log_semiring: bool = True, use_double_scores: bool = False):
