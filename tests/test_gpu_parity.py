@@ -955,3 +955,41 @@ def test_cfg5_benched_workload_bit_exact_against_c_oracle(oracle_lib, S, T):
     assert np.array_equal(scores, want_s) and np.array_equal(trop, want_s)
     assert np.array_equal(arcs, want_a)
     assert best_path_checksum(scores, arcs) == best_path_checksum(want_s, want_a)
+
+
+# ---- hub form: topologies used as denominators over a large table (sweep_hub_kernel / post_hub_kernel) ----------------
+
+HUB_TOPOS = ["2state", "2state-1", "3state-skip", "3state-skip-1", "3state-skip-2", "mmictc", "mmictc-1"]
+HUB_PATHS = {
+    "hub": {"WF_NO_LIN_SWEEP": "2"},                                          # (below 1024 states the lane-per-state sweep would take it)
+    "hub_check_kernel": {"WF_NO_LIN_SWEEP": "2", "WF_NO_POST_CHECK": "1"},
+    "hub_then_fallback": {"WF_NO_LIN_SWEEP": "2", "WF_FORCE_FALLBACK": "1"},
+    "hub_check_kernel_then_fallback": {"WF_NO_LIN_SWEEP": "2", "WF_NO_POST_CHECK": "1", "WF_FORCE_FALLBACK": "1"},
+    "linbig": {"WF_NO_LIN_SWEEP": "2", "WF_NO_HUB_SWEEP": "1"},
+}
+
+
+@pytest.mark.parametrize("path", sorted(HUB_PATHS))
+@pytest.mark.parametrize("topo", HUB_TOPOS)
+def test_hub_form_denominators(topo, path):
+    from waterfall_amd.csrc_layout import HDR_WORDS, INFO_WORDS
+    c = util.random_case(600 + len(topo), topo, B=4, T=45, L=4, P=300, den=True)
+    info = c["fsa"].blob_host()[HDR_WORDS:HDR_WORDS + INFO_WORDS]
+    assert info[46] in (2, 3) and info[47] == 300          # WF_I_HUB_G / WF_I_HUB_NG: the hub form was found
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+
+    def run():
+        tot, grad = fused_logsum(c["fsa"], c["lp"], c["segs"])
+        loss, agrad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
+        with torch.no_grad():
+            fwd, _ = run_hip(c["fsa"], c["lp"], c["segs"], "none", need_grad=False)
+        return tot, grad, loss, agrad, fwd
+    tot, grad, loss, agrad, fwd = _with_env(HUB_PATHS[path], run)
+    for got_loss, got_grad in ((-tot, grad), (loss, agrad)):
+        np.testing.assert_allclose(got_loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+        np.testing.assert_allclose(got_grad, wgrad, atol=GRAD_ATOL)
+    np.testing.assert_allclose(fwd, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    for b in range(4):
+        T = int(c["segs"][b, 2])
+        np.testing.assert_allclose(grad[b, :T].sum(-1), -1.0, atol=2e-3)
+        assert np.all(grad[b, T:] == 0)

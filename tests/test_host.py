@@ -168,7 +168,7 @@ def test_layout_mirror_in_sync_with_header():
     import re
     from waterfall_amd import csrc_layout as L
     h = open(os.path.join(ROOT, "waterfall_amd", "csrc", "wf_internal.h")).read()
-    assert {k: int(v) for k, v in re.findall(r"WF_I_([A-Z_]+) = (\d+)", h)} == L.INFO
+    assert {k: int(v) for k, v in re.findall(r"WF_I_([A-Z_0-9]+) = (\d+)", h)} == L.INFO
     assert int(re.search(r"#define WF_INFO_WORDS (\d+)", h).group(1)) == L.INFO_WORDS
 
 

@@ -55,6 +55,7 @@ inline size_t fsa_words_bound(size_t S, size_t A) {
     w += 2 * pad4(S) + pad4(A);              // finb_log, finb_max, arc_src
     if (S - 1 <= 64 * WF_BAND_MAX_R)         // banded form is only built for graphs one wavefront can hold
         w += pad4(S) + 2 * pad4(S * (WF_BAND_MAX_BW + 1) * WF_BAND_MAX_M * 2);
+    w += pad4(WF_HUB_MAX_NC) + pad4((WF_HUB_MAX_G + 1) * (WF_HUB_MAX_G + 1) * WF_HUB_MAX_NC) + pad4(A);   // hub form
     return w;
 }
 
@@ -323,6 +324,97 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
                 }
             }
         }
+    }
+    // ---- hub form (wf_internal.h WF_I_HUB_*): a topology used as denominator over a large table
+    I[WF_I_HUB_G] = 0;
+    if (we && direct && S - 2 >= 256 && NF >= 1) {
+        bool fin_ok = true;
+        for (int a : X.fin) if (arcs[4 * (size_t)a] != 0) fin_ok = false;
+        if (fin_ok && NF == 1)
+            for (int G = 1; G <= WF_HUB_MAX_G && !I[WF_I_HUB_G]; ++G) {
+                if ((S - 2) % G) continue;
+                const int NG = (S - 2) / G, W = G + 1;
+                auto loc = [&](int st, int* g) { if (st == 0) { *g = -1; return G; } *g = (st - 1) / G; return (st - 1) % G; };
+                // column classes from group 0 (sorted), stride from group 1
+                int c0[WF_HUB_MAX_NC + 1], nc = 0;
+                bool ok = true;
+                for (int j = 0; j < A && ok; ++j) {
+                    const int32_t* r = arcs + 4 * (size_t)X.em[j];
+                    int gs, gd;
+                    const int ls = loc(r[0], &gs), ld = loc(r[1], &gd);
+                    (void)ls; (void)ld;
+                    if (gs >= 0 && gd >= 0 && gs != gd) { ok = false; break; }   // an arc between two groups
+                    const int g = gs >= 0 ? gs : gd;
+                    if (g != 0) continue;
+                    bool have = false;
+                    for (int c = 0; c < nc; ++c) if (c0[c] == r[2]) have = true;
+                    if (!have) { if (nc == WF_HUB_MAX_NC) { ok = false; break; } c0[nc++] = r[2]; }
+                }
+                if (!ok || nc == 0) continue;
+                std::sort(c0, c0 + nc);
+                int cs = 0;
+                if (NG >= 2) {   // the smallest column used by group 1 belongs to class 0
+                    int m1 = INT32_MAX;
+                    for (int j = 0; j < A; ++j) {
+                        const int32_t* r = arcs + 4 * (size_t)X.em[j];
+                        int gs, gd;
+                        loc(r[0], &gs); loc(r[1], &gd);
+                        if ((gs >= 0 ? gs : gd) == 1) m1 = std::min(m1, (int)r[2]);
+                    }
+                    if (m1 == INT32_MAX) continue;
+                    cs = m1 - c0[0];
+                    if (cs <= 0) continue;
+                }
+                // count tables: [group][(dst*W + src)*nc + c]; every group must equal group 0; hub self-loops are given to the
+                // group that owns their column, the rest are extras
+                const int TS = W * W * nc;
+                X.fillf.assign((size_t)TS * 2, 0);          // [0..TS): group 0's table, [TS..2TS): the current group's
+                X.fillb.assign(NG, 0);                        // arcs seen per group
+                std::vector<int32_t>& cntg = X.indeg;         // per group per table entry: built lazily, compared at the end
+                cntg.assign((size_t)NG * TS, 0);
+                X.order.clear();                              // extra hub self-loop columns
+                auto cls = [&](int col, int g) { for (int c = 0; c < nc; ++c) if (c0[c] + (int64_t)g * cs == col) return c; return -1; };
+                for (int j = 0; j < A && ok; ++j) {
+                    const int32_t* r = arcs + 4 * (size_t)X.em[j];
+                    int gs, gd;
+                    const int ls = loc(r[0], &gs), ld = loc(r[1], &gd);
+                    int g = gs >= 0 ? gs : gd;
+                    if (g < 0) {   // hub self-loop: owned by a group when its column is one of that group's
+                        g = -1;
+                        for (int c = 0; c < nc && g < 0; ++c) {
+                            const int64_t d = (int64_t)r[2] - c0[c];
+                            if (NG == 1 ? d == 0 : (d >= 0 && d % cs == 0 && d / cs < NG)) g = NG == 1 ? 0 : (int)(d / cs);
+                        }
+                        if (g < 0) { X.order.push_back(r[2]); continue; }
+                    }
+                    const int c = cls(r[2], g);
+                    if (c < 0) { ok = false; break; }
+                    cntg[(size_t)g * TS + (ld * W + ls) * nc + c]++;
+                }
+                for (int g = 1; g < NG && ok; ++g)
+                    if (memcmp(&cntg[(size_t)g * TS], &cntg[0], sizeof(int32_t) * TS)) ok = false;
+                // the posterior kernel writes exactly the columns of the hub form: they must be all of 0..K-1, each once
+                {
+                    std::vector<int32_t>& seen = X.dist;
+                    seen.assign(K, 0);
+                    for (int g = 0; g < NG && ok; ++g)
+                        for (int c = 0; c < nc; ++c) {
+                            const int64_t col = c0[c] + (int64_t)g * cs;
+                            if (col >= K || seen[col]++) { ok = false; break; }
+                        }
+                    for (size_t e = 0; e < X.order.size() && ok; ++e)
+                        if (X.order[e] >= K || seen[X.order[e]]++) ok = false;
+                    if (ok && (int64_t)NG * nc + (int64_t)X.order.size() != K) ok = false;
+                }
+                if (!ok || cur + pad4(nc) + pad4(TS) + pad4(X.order.size()) > limit) continue;
+                const int o_c0 = take(nc), o_cf = take(TS), o_x = take(X.order.size());
+                for (int c = 0; c < nc; ++c) B[o_c0 + c] = c0[c];
+                for (int e = 0; e < TS; ++e) { const float f = (float)cntg[e]; memcpy(&B[o_cf + e], &f, 4); }
+                for (size_t e = 0; e < X.order.size(); ++e) B[o_x + e] = X.order[e];
+                I[WF_I_HUB_G] = G; I[WF_I_HUB_NG] = NG; I[WF_I_HUB_NC] = nc; I[WF_I_HUB_C0] = o_c0; I[WF_I_HUB_CS] = cs;
+                I[WF_I_HUB_COEF] = o_cf; I[WF_I_HUB_NX] = (int32_t)X.order.size(); I[WF_I_HUB_XCOL] = o_x;
+                I[WF_I_HUB_FINW] = arcs[4 * (size_t)X.fin[0] + 3];
+            }
     }
     return WF_OK;
 }

@@ -6,7 +6,7 @@
 
 #define WF_BLOB_MAGIC 0x31474657  // "WFG1"
 #define WF_HDR_WORDS 8
-#define WF_INFO_WORDS 48
+#define WF_INFO_WORDS 64
 // A state whose in-degree (forward sweep) or out-degree (backward sweep) exceeds this is reduced
 // cooperatively by the whole workgroup instead of by one lane.
 #define WF_HEAVY_DEG 16
@@ -69,7 +69,24 @@ enum {
     WF_I_BANDB = 44,       // same for the backward sweep in reversed positions p' = S-2-p:
                            // arcs OUT OF the state at p' to p' - d (reversed), i.e. to position p + d
     WF_I_BAND_WE = 45,     // 1: every emitting arc has weight 0 ("weights elided": all training topologies)
+    // ---- hub form (sweep_hub_kernel / post_hub_kernel): a topology used as denominator over a large table.  State 0 is
+    // the hub; the other non-final states fall into NG groups of G consecutive states (group g = states 1 + g*G ..) that
+    // are connected only to the hub and among themselves, all with the same arc pattern; the label of an arc of group g
+    // is column C0[c] + g*CS for one of NC column classes c.  (mmictc: G = 2, classes p_0, p_1; 3state-skip: G = 2,
+    // classes p_0, p_1, p_2.)  All weights 0, only the hub is final.
+    WF_I_HUB_G = 46,       // states per group (0: the graph has no hub form)
+    WF_I_HUB_NG = 47,
+    WF_I_HUB_NC = 48,      // column classes per group (<= WF_HUB_MAX_NC)
+    WF_I_HUB_C0 = 49,      // [NC] column of class c in group 0
+    WF_I_HUB_CS = 50,      // column stride between consecutive groups
+    WF_I_HUB_COEF = 51,    // float [(G+1)*(G+1)][NC]: number of arcs src -> dst with class c at [(dst*(G+1) + src)*NC + c];
+                           // index G = the hub (hub -> hub: the hub self-loops labelled with a group's columns)
+    WF_I_HUB_NX = 52,      // hub self-loops whose label belongs to no group (<blk>)
+    WF_I_HUB_XCOL = 53,    // [NX] their columns
+    WF_I_HUB_FINW = 54,    // float bits: weight of the hub's final arc
 };
+#define WF_HUB_MAX_G 3
+#define WF_HUB_MAX_NC 4
 // limits of the banded sweep (template instantiations in wf_kernels.hip)
 #define WF_BAND_MAX_BW 4
 #define WF_BAND_MAX_M 2

@@ -30,6 +30,7 @@
 
 #include <vector>
 
+#include <type_traits>
 #include <utility>
 
 #include "../../include/wf_dwfst.h"
@@ -123,6 +124,8 @@ struct SweepArgs {
     int arcs_lds_words;  // words reserved for the LDS copy of the CSR arrays
     int hcap;      // heavy states reduced per cooperative round (sizes the LDS reduction scratch)
     int tot_double;
+    int32_t* flag_clear;  // sweep_hub_kernel (no gather kernel in front of it): the utterance's fallback flag, cleared
+    double* cmax_w;       // sweep_hub_kernel: the per-frame normalisers c_t (all 0) for the kernels that read them
     // sweep_band_kernel: workgroups >= nsweep of the launch zero-fill the gradient box (n4 float4 + a tail) instead of
     // sweeping -- the fill that otherwise runs beside the sweep on a side stream, without the fork / join events
     // (two dependent queue packets each).  nsweep == gridDim.x: no fill attached.
@@ -1495,6 +1498,290 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_linbig_kernel(SweepArgs p) 
 }
 
 // ------------------------------------------------------------------------------------------
+// Hub sweep (sweep_hub_kernel): the probability-domain forward / backward recursion of a TOPOLOGY USED AS DENOMINATOR over
+// a large table (cfg4: mmictc / 3state-skip at P = 5000, S = 10 002, fan-in(0) = 10 001 - 15 001), in the hub form that
+// wf_graph_prepare detects (wf_internal.h WF_I_HUB_*): state 0 is the hub, every other state belongs to one of NG groups
+// of G consecutive states (one group per phone) that talk only to the hub and among themselves, with the same arc pattern
+// in every group and labels at a regular stride.
+//
+// One 1024-lane workgroup per (utterance, direction).  A lane OWNS groups (tid + k * 1024): their G state values stay in
+// fp64 registers for the whole sweep, their emissions are read straight from the log_probs row (adjacent lanes: adjacent
+// columns; no gather kernel, no probability arena) two frames ahead, exp'd by the lane, and combined through the group's
+// small transition pattern (coefficient table in scalar registers).  The ONLY cross-lane traffic of a frame is the hub:
+// each lane's contribution is summed with a DPP wave reduction and 16 LDS words, one barrier per frame -- against
+// 72 scattered LDS reads per lane and frame in sweep_linbig_kernel (5.7 us per frame step -> see DESIGN.md).
+// Rows leave as fp64 scaled probabilities with one power-of-two shift per frame, the format of sweep_linbig_kernel
+// (group 1, lag 0; c_t = 0: the emissions are not normalised per frame), so the row check, the fallback and the
+// posterior kernels are shared.
+// ------------------------------------------------------------------------------------------
+constexpr int kHubCompute = 768;   // lanes that own groups (12 wavefronts); the other 4 wavefronts of the workgroup load
+constexpr int kHubSlots = 7;       // groups per compute lane: NG <= 7 * 768
+constexpr int kHubLoad = kMaxThreads - kHubCompute;
+
+// The arc patterns of the reference's two-state-per-phone topologies (utils/get_token_fst_*_k2.py) in hub form, as compile-
+// time entry lists "new value of i += P[class c] * value of j" (forward direction; i, j: 0 = x, 1 = x + 1, 2 = the hub),
+// encoded i * 16 + j * 4 + c, every arc count 1.  With the pattern known at compile time a group's step is one fp64 FMA
+// per arc and one conversion per class; any other pattern (PAT = -1) evaluates the whole coefficient table (3x the work).
+constexpr int kHubPatMax = 8;
+constexpr int hub_e(int i, int j, int c) { return i * 16 + j * 4 + c; }
+struct HubPattern { int n; int e[kHubPatMax]; };
+constexpr HubPattern kHubPatterns[] = {
+    {6, {hub_e(0, 2, 0), hub_e(1, 0, 1), hub_e(1, 1, 1), hub_e(2, 0, 1), hub_e(2, 1, 1), hub_e(2, 2, 0)}},                  // 0 mmictc
+    {7, {hub_e(0, 2, 0), hub_e(0, 0, 0), hub_e(1, 0, 1), hub_e(1, 1, 1), hub_e(2, 0, 1), hub_e(2, 1, 1), hub_e(2, 2, 0)}},  // 1 mmictc-1
+    {6, {hub_e(0, 2, 0), hub_e(0, 0, 0), hub_e(1, 0, 1), hub_e(1, 1, 1), hub_e(2, 0, 1), hub_e(2, 1, 1)}},                  // 2 2state
+    {5, {hub_e(0, 2, 0), hub_e(1, 0, 1), hub_e(1, 1, 1), hub_e(2, 0, 1), hub_e(2, 1, 1)}},                                  // 3 2state-1
+    {5, {hub_e(0, 2, 0), hub_e(1, 0, 1), hub_e(1, 1, 1), hub_e(2, 0, 2), hub_e(2, 1, 2)}},                                  // 4 3state-skip
+};
+constexpr int kHubNumPatterns = 5;
+
+// the G values of one group as one store (rows are 8-byte aligned; the groups start at state 1)
+template <int G> struct __attribute__((packed, aligned(8))) HubRow { double v[G]; };
+
+// PAT: index into kHubPatterns (G = 2), or -1: the pattern is only known at run time.
+template <int G, int NC, int PAT>
+__global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
+    constexpr int W = G + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* red = (double*)smem;          // [2][16] per-wave partial sums of the hub, by step parity
+    int* rexp = (int*)(red + 32);         // [2][16] per-wave exponent maxima
+    float* pbuf = (float*)(rexp + 32);    // [nb][kp] log_probs rows of nb consecutive frames (frame f in buffer f % nb)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int u = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int fsa = uni((int)U[WF_U_FSA]), T = uni((int)U[WF_U_T]);
+    const int32_t* blob = p.blob;
+    const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
+    const int S = uni(I[WF_I_S]), K = uni(I[WF_I_K]);
+    if (dir == 0 && tid == 0) p.flag_clear[u] = 0;
+    if (T < uni(I[WF_I_MINLEN])) {   // structurally infeasible: no sweep needed
+        if (dir == 0 && tid == 0) {
+            ((float*)p.tot)[u] = -INFINITY;
+            p.totd[u] = (double)-INFINITY;
+            p.tot2[u] = (double)-INFINITY;
+            p.ctot2[u] = 0.0;
+        }
+        return;
+    }
+    const int kp = p.kpad;   // pitch of one probability row in the LDS (>= K)
+    const float* lpbase = p.lp + uni(U[WF_U_SEQ]) * p.strideB + uni(U[WF_U_START]) * p.strideT;
+    if (tid < 32) { red[tid] = 0.0; rexp[tid] = 0; }
+
+    if (wave >= kHubCompute / 64) {
+        // =============================== loader wavefronts ===============================
+        // Only loads here, only stores in the compute wavefronts: loads and stores share one in-order counter (vmcnt), so
+        // a wavefront that does both waits for its earlier row stores to be acknowledged (~2 us under this load) whenever
+        // it needs a loaded value -- measured: 5.2 us per frame step with everything in one wavefront.
+        // The log_probs row of a frame goes straight into the LDS (LDS-DMA: 64 consecutive floats per wave-instruction, no
+        // registers); with three row buffers frame s + 2 is requested while frame s is being used, and its arrival is
+        // awaited a whole frame step later.  Raw s_barrier: __syncthreads() would drain the DMAs in flight.
+        const int lw = wave - kHubCompute / 64;
+        const int nchunk = (K + 63) >> 6;
+        const int nb = p.chunk;   // row buffers in the LDS (2 or 3)
+        auto issue = [&](const int frame) __attribute__((always_inline)) {
+            const float* row = lpbase + (int64_t)(dir ? T - 1 - frame : frame) * p.strideT;
+            float* dst = pbuf + (size_t)(frame % nb) * kp;
+            if (p.ablate & 2) return;   // (timing aid: no loads)
+            for (int c = lw; c < nchunk; c += kHubLoad / 64)
+                __builtin_amdgcn_global_load_lds(row + min(64 * c + lane, K - 1), (__attribute__((address_space(3))) float*)(dst + 64 * c), 4, 0, 0);
+        };
+        if (T > 0) issue(0);
+        if (nb == 3) {
+            if (T > 1) issue(1);
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+            __builtin_amdgcn_s_barrier();         // the initial row is stored, frame 0 is staged
+            for (int step = 0; step < T; ++step) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);   // frame step + 1 has landed (requested one interval ago)
+                if (step + 2 < T) issue(step + 2);    // into the buffer of frame step - 1, free since the last barrier
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();
+            for (int step = 0; step < T; ++step) {
+                if (step + 1 < T) issue(step + 1);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        return;
+    }
+    // =============================== compute wavefronts ===============================
+    const int NG = uni(I[WF_I_HUB_NG]), cs = uni(I[WF_I_HUB_CS]), NX = uni(I[WF_I_HUB_NX]);
+    const int32_t* c0p = blob + uni(I[WF_I_HUB_C0]);
+    const float* cfp = (const float*)(blob + uni(I[WF_I_HUB_COEF]));
+    const int32_t* xcol = blob + uni(I[WF_I_HUB_XCOL]);
+    // coefficient of class c in "new value of i += coefficient * value of j" (i, j in 0..G, G = the hub): the arcs j -> i in
+    // the forward sweep, i -> j in the backward sweep.  Uniform values: they live in scalar registers.
+    float cf[W][W][NC];
+    unsigned present = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int e = dir ? (j * W + i) : (i * W + j);
+                cf[i][j][c] = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, cfp[e * NC + c])));
+                if (cf[i][j][c] != 0.f) present |= 1u << (i * W + j);
+            }
+    present = (unsigned)uni((int)present);
+    int c0[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) c0[c] = uni(c0p[c]);
+    const int nslot = (NG + kHubCompute - 1) / kHubCompute;
+    double* arena = (double*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
+    double* goff = (dir ? p.boff : p.aoff) + uni(U[WF_U_OFFS]);
+    const float finw = __builtin_bit_cast(float, uni(I[WF_I_HUB_FINW]));
+    const int xc = NX > 0 ? xcol[min(tid, NX - 1)] : 0;
+
+    // ---- initial row: alpha_0 = delta(hub); beta_T = the hub's final weight
+    double a[kHubSlots][G];
+#pragma unroll
+    for (int k = 0; k < kHubSlots; ++k)
+#pragma unroll
+        for (int i = 0; i < G; ++i) a[k][i] = 0.0;
+    double h = dir ? exp((double)finw) : 1.0;
+    {
+        double* row = arena + (int64_t)(dir ? T : 0) * S;
+        for (int s2 = tid; s2 < S; s2 += kHubCompute) row[s2] = s2 == 0 ? h : 0.0;
+        if (tid == 0) goff[0] = 0.0;
+        if (dir == 0) {   // c_t = 0 for the kernels that read the per-frame normaliser
+            double* crow = p.cmax_w + uni(U[WF_U_ROW0]);
+            for (int t = tid; t < T; t += kHubCompute) crow[t] = 0.0;
+        }
+    }
+    // LDS offsets of this lane's emissions inside a row buffer, per owned group and class; a lane without a group in its last
+    // slot reads the buffer's pad word (-inf: probability 0), so that its values stay 0 with no masking in the frame loop
+    const int nb = p.chunk;
+    int poff[kHubSlots][NC];
+#pragma unroll
+    for (int k = 0; k < kHubSlots; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int g = tid + k * kHubCompute;
+            poff[k][c] = g < NG ? c0[c] + g * cs : kp - 1;
+        }
+    if (tid < nb) pbuf[(size_t)tid * kp + kp - 1] = -INFINITY;   // (the DMA pieces end before the pad word)
+    __syncthreads();   // frame 0 is staged
+    double cum = 0.0;
+    // the frame loop, once per direction at compile time (TR: the backward sweep uses the transposed pattern)
+    auto frames = [&](const auto tr) __attribute__((always_inline)) {
+        constexpr bool TR = decltype(tr)::value;
+        int sh = 0, ib = 0;
+        for (int step = 0; step < T; ++step) {
+            const float* pc = pbuf + (size_t)ib * kp;
+            ib = ib + 1 == nb ? 0 : ib + 1;
+            const int f = TR ? T - 1 - step : step;
+            double* srow = arena + (int64_t)(TR ? f : f + 1) * S;
+            cum += (double)sh;
+            if (tid == 0) goff[step + 1] = cum;
+            double part = 0.0;      // this lane's share of the hub's new value
+            double selfd = 0.0;     // sum of the probabilities on hub self-loops (times the hub's value below)
+            int emine = 0;
+            const int shc = min(max(sh, -16), 64);   // rides in the exp2 argument (fp32: no underflow for lp > -43, no overflow)
+            const int shr = sh - shc;                // the rest, by ldexp (uniform, rare: the first frames)
+            const float shf = (float)shc;
+#pragma unroll
+            for (int k = 0; k < kHubSlots; ++k) {
+                if (k < nslot) {
+                    // exp(lp) * 2^shf: the row's rescaling rides in the exponent argument
+                    float pr[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) pr[c] = __builtin_amdgcn_exp2f(fmaf(pc[poff[k][c]], kLog2e, shf));
+                    double nv[G];
+#pragma unroll
+                    for (int i = 0; i < G; ++i) nv[i] = 0.0;
+                    if (PAT >= 0) {
+                        constexpr HubPattern pat = kHubPatterns[PAT >= 0 ? PAT : 0];
+                        double prd[NC];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) prd[c] = (double)pr[c];
+#pragma unroll
+                        for (int e = 0; e < pat.n; ++e) {
+                            const int ii = pat.e[e] >> 4, jj = (pat.e[e] >> 2) & 3, c = pat.e[e] & 3;
+                            const int i = TR ? jj : ii, j = TR ? ii : jj;
+                            if (i == G && j == G) selfd += prd[c < NC ? c : 0];
+                            else {
+                                const double vj = j == G ? h : a[k][j < G ? j : 0];
+                                if (i == G) part = fma(prd[c < NC ? c : 0], vj, part);
+                                else nv[i < G ? i : 0] = fma(prd[c < NC ? c : 0], vj, nv[i < G ? i : 0]);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < W; ++i)
+#pragma unroll
+                            for (int j = 0; j < W; ++j) {
+                                if (present & (1u << (i * W + j))) {   // uniform
+                                    float cp = cf[i][j][0] * pr[0];
+#pragma unroll
+                                    for (int c = 1; c < NC; ++c) cp = fmaf(cf[i][j][c], pr[c], cp);
+                                    if (i == G && j == G) selfd += (double)cp;
+                                    else {
+                                        const double vj = j == G ? h : a[k][j < G ? j : 0];
+                                        if (i == G) part = fma((double)cp, vj, part);
+                                        else nv[i < G ? i : 0] = fma((double)cp, vj, nv[i < G ? i : 0]);
+                                    }
+                                }
+                            }
+                    }
+                    if (shr) {   // a real branch (the empty asm keeps the compiler from turning it into an unconditional ldexp + select)
+                        asm volatile("");
+#pragma unroll
+                        for (int i = 0; i < G; ++i) nv[i] = ldexp(nv[i], shr);
+                    }
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        a[k][i] = nv[i];
+                        emine = max(emine, f64_exp_field(nv[i]));
+                    }
+                    const int g = tid + k * kHubCompute;
+                    if (g < NG && !(p.ablate & 1)) {   // (ablate: timing aid)
+                        HubRow<G> v;
+#pragma unroll
+                        for (int i = 0; i < G; ++i) v.v[i] = nv[i];
+                        *(HubRow<G>*)(srow + 1 + g * G) = v;
+                    }
+                }
+            }
+            if (tid < NX) selfd += (double)__builtin_amdgcn_exp2f(fmaf(pc[xc], kLog2e, shf));
+            part = fma(h, selfd, part);
+            if (shr) { asm volatile(""); part = ldexp(part, shr); }
+            part = wave_sum_d(part);
+            emine = wave_max_i(emine);
+            const int par = (step & 1) * 16;
+            if (lane == 0) { red[par + wave] = part; rexp[par + wave] = emine; }
+            __syncthreads();
+            static_assert(kHubCompute / 64 == 12, "the reduction below sums twelve partial values");
+            double r[12];
+            int ex[12];
+#pragma unroll
+            for (int w = 0; w < 12; ++w) { r[w] = red[par + w]; ex[w] = rexp[par + w]; }
+            // a fixed tree (the same in every lane: the hub's value is uniform), four additions deep
+            const double hn = (((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))) + ((r[8] + r[9]) + (r[10] + r[11]));
+            int em = max(max(max(ex[0], ex[1]), max(ex[2], ex[3])), max(max(ex[4], ex[5]), max(ex[6], ex[7])));
+            em = max(em, max(max(ex[8], ex[9]), max(ex[10], ex[11])));
+            h = hn;
+            em = max(em, f64_exp_field(hn));
+            sh = uni(em > 0 ? (1023 + kLinBias) - em : 0);   // next row: maximum back to 2^kLinBias
+            if (tid == 0) srow[0] = hn;
+        }
+    };
+    if (dir) frames(std::true_type{}); else frames(std::false_type{});
+    if (dir == 0 && tid == 0) {
+        const double fsum = h * exp((double)finw);
+        const bool dead = !(fsum > 0.0);
+        const double tot2 = dead ? (double)-INFINITY : log2(fsum) - cum;
+        const double tot = dead ? (double)-INFINITY : tot2 * kLn2;
+        p.tot2[u] = tot2;
+        p.ctot2[u] = 0.0;
+        p.totd[u] = tot;
+        ((float*)p.tot)[u] = (float)tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Banded wave sweep: the linear-domain forward-backward recursion of a numerator graph with NO LDS
 // round trip of the state vector and NO barrier on the critical path.
 //
@@ -2758,6 +3045,7 @@ __global__ void __launch_bounds__(256) post_big_kernel(PostArgs p) {
     const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
     const double tot = has ? p.totd[u] : 0.0;
     const int t = f - start;
+    if (p.pass == 1 && !(has && p.flag[u])) return;   // after post_hub_kernel: only the utterances it left to this kernel
     if (!has || tot == (double)-INFINITY || t < 0 || t >= T) {
         if (!p.skip_zero) zero_span(grow, V, tid, 256);
         return;
@@ -2816,6 +3104,114 @@ __global__ void __launch_bounds__(256) post_big_kernel(PostArgs p) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) acc += shfl_xor(acc, o);
             if (lane == 0) grow[direct ? kk : labels[kk]] = gs * acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// post_hub_kernel: gradient rows of a graph in hub form (see sweep_hub_kernel).  One 256-lane workgroup per (frame,
+// sequence); a lane takes groups tid, tid + 256, ...: the group's alpha_t / beta_{t+1} values, its NC log-probs and its
+// NC gradient entries are all contiguous runs shared with the neighbouring lanes -- a pure streaming kernel (read the
+// alpha row, the beta row and the log_probs row, write the gradient row; nothing is gathered through arc lists, where
+// post_big_kernel re-reads 12 B per arc from L2 in every workgroup).  All arcs carrying a label sit in one group, so the
+// per-label sums are lane-local and in a fixed order (bit-stable).  Every column of the row is written (the hub form
+// covers columns 0..K-1; K..V-1 are zeroed), so no zero-fill is needed.
+// pass 0: the frame's posteriors must sum to 1, else flag_w[u] is set (the log-semiring fallback + post_big_kernel redo
+// the utterance afterwards); pass -1: utterances flagged by check_kernel are left to post_big_kernel.
+// ------------------------------------------------------------------------------------------
+template <int G, int NC>
+__global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
+    constexpr int W = G + 1;
+    __shared__ float rchk[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x, q = blockIdx.y;
+    float* grow = p.grad + (int64_t)q * p.strideB + (int64_t)f * p.strideT;
+    const int V = p.V;
+    const int u = p.seq2utt[q];
+    const bool has = u >= 0;
+    const int64_t* U = p.utt + (int64_t)(has ? u : 0) * WF_U_WORDS;
+    const int start = (int)U[WF_U_START], T = (int)U[WF_U_T];
+    const double tot2 = has ? p.tot2[u] : 0.0;
+    const int t = f - start;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    if (p.pass == 0 && has && f == 0 && tid == 0 && tot2 == (double)-INFINITY && T >= I[WF_I_MINLEN]) p.flag_w[u] = 1;
+    if (has && p.pass != 0 && p.flag[u]) return;   // log-domain rows: post_big_kernel's
+    if (!has || tot2 == (double)-INFINITY || t < 0 || t >= T) {
+        zero_span(grow, V, tid, 256);
+        return;
+    }
+    const int S = I[WF_I_S], K = I[WF_I_K];
+    const int NG = I[WF_I_HUB_NG], cs = I[WF_I_HUB_CS], NX = I[WF_I_HUB_NX];
+    const int32_t* c0p = p.blob + I[WF_I_HUB_C0];
+    const float* cfp = (const float*)(p.blob + I[WF_I_HUB_COEF]);
+    const int32_t* xcol = p.blob + I[WF_I_HUB_XCOL];
+    float cf[W][W][NC];
+    unsigned present = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                cf[i][j][c] = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, cfp[(i * W + j) * NC + c])));
+                if (cf[i][j][c] != 0.f) present |= 1u << (i * W + j);
+            }
+    present = (unsigned)uni((int)present);
+    int c0[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) c0[c] = uni(c0p[c]);
+    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    const float* erow = p.lp + (int64_t)q * p.strideB + (int64_t)(start + t) * p.strideT;
+    const float gs = p.gscale ? p.gscale[u] : 1.f;
+    // alpha row t came from forward step t-1, beta row t+1 from backward step T-2-t (one shift per step, c_t = 0)
+    const double kk = -tot2 - p.aoff[U[WF_U_OFFS] + lin_shift_index(t - 1, 1, 0)] - p.boff[U[WF_U_OFFS] + lin_shift_index(T - 2 - t, 1, 0)];
+    // alpha^ * beta^ * 2^kk: alpha^ and beta^ sit near 2^800 each, kk near -1600; split the scale over both factors
+    const int k1 = (int)floor(kk * 0.5);
+    const double sa = exp2(kk - (double)k1 - (double)k1);   // in [1, 4): the fractional part
+    const double ha = ldexp(arow[0] * sa, k1), hb = ldexp(brow[0], k1);
+    float chk = 0.f;
+    for (int g = tid; g < NG; g += 256) {
+        double av[W], bv[W];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            av[i] = ldexp(arow[1 + g * G + i] * sa, k1);
+            bv[i] = ldexp(brow[1 + g * G + i], k1);
+        }
+        av[G] = ha; bv[G] = hb;
+        float pr[NC], acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { pr[c] = __builtin_amdgcn_exp2f(erow[c0[c] + g * cs] * kLog2e); acc[c] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                if (present & (1u << (i * W + j))) {   // arcs j -> i: alpha_t[j] * beta_{t+1}[i]
+                    const float w = (float)(av[j] * bv[i]);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[c] = fmaf(cf[i][j][c], w, acc[c]);
+                }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float val = acc[c] * pr[c];
+            chk += val;
+            grow[c0[c] + g * cs] = gs * val;
+        }
+    }
+    for (int e = tid; e < NX; e += 256) {
+        const int col = xcol[e];
+        const float val = (float)(ha * hb) * __builtin_amdgcn_exp2f(erow[col] * kLog2e);
+        chk += val;
+        grow[col] = gs * val;
+    }
+    if (K < V) zero_span(grow + K, V - K, tid, 256);
+    if (p.pass == 0) {
+        chk = wave_sum(chk);
+        if (lane == 0) rchk[wv] = chk;
+        __syncthreads();
+        if (tid == 0) {
+            const float sum = (rchk[0] + rchk[1]) + (rchk[2] + rchk[3]);
+            if (p.force || !(fabsf(sum - 1.f) <= kCheckTol)) p.flag_w[u] = 1;
         }
     }
 }
@@ -3180,6 +3576,9 @@ struct Plan {
     bool shared = false;    // ... and the whole batch uses one graph (forward-only calls): kNB utterances per lane
     bool one_fsa = true;
     bool linbig = false;    // lin, by sweep_linbig_kernel (emission probabilities kept as fp32)
+    bool hub = false;       // lin, by sweep_hub_kernel / post_hub_kernel: every graph is in hub form with the same (G, NC)
+    int hub_g = -1, hub_nc = 0, hub_ng = 0;   // (-1: no graph seen yet; 0: not all in the same hub form)
+    int hub_pat = -2;                         // index into kHubPatterns when every graph has that pattern (-2: none seen, -1: other)
     size_t off_big = 0, off_Et = 0;
     int64_t nstates = 0;
     int nheavy_in_max = 0, nheavy_out_max = 0;
@@ -3209,7 +3608,7 @@ constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where not
 struct Hooks {
     int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
         zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache,
-        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream;
+        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern;
 };
 Hooks g_hooks;
 bool g_hooks_loaded = false;
@@ -3231,6 +3630,7 @@ void load_hooks() {
     h.post_profile = env_int("WF_POST_PROFILE", 0); h.sweep_profile = env_int("WF_SWEEP_PROFILE", 0);
     h.quad_r = env_int("WF_QUAD_R", 0);
     h.no_post_check = env_int("WF_NO_POST_CHECK", 0); h.fill_side_stream = env_int("WF_FILL_SIDE_STREAM", 0);
+    h.no_hub = env_int("WF_NO_HUB_SWEEP", 0); h.no_hub_pattern = env_int("WF_NO_HUB_PATTERN", 0);
     g_hooks = h;
     g_hooks_loaded = true;
 }
@@ -3241,6 +3641,7 @@ inline const Hooks& hk() {
 struct BandSel { bool ok = false; int R = 0, BW = 0, M = 1, grp = 0; bool we = false; bool gen = false; };
 BandSel band_config(const Plan& P);
 bool linbig_config(const Plan& P);
+bool hub_config(const Plan& P);
 bool post_small_fits(const Plan& P);
 
 // dbl_exact: WF_DOUBLE_ACC (k2 use_double_scores=True): exp/log in fp64 too, log-semiring sweep only
@@ -3298,6 +3699,26 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         P->band_sn = std::max(P->band_sn, (int)I[WF_I_S] - 1);
         P->band_m = std::max(P->band_m, (int)I[WF_I_BAND_M]);
         if (!I[WF_I_BAND_WE]) P->band_we = false;
+        {
+            int pat = -1;
+            if (I[WF_I_HUB_G] == 2) {   // does the coefficient table equal one of the compile-time patterns?
+                const int nc = I[WF_I_HUB_NC];
+                const float* cfh = (const float*)(H + I[WF_I_HUB_COEF]);
+                for (int q = 0; q < kHubNumPatterns && pat < 0; ++q) {
+                    float want[9 * WF_HUB_MAX_NC] = {};
+                    bool fits = true;
+                    for (int e = 0; e < kHubPatterns[q].n; ++e) {
+                        const int i = kHubPatterns[q].e[e] >> 4, j = (kHubPatterns[q].e[e] >> 2) & 3, c = kHubPatterns[q].e[e] & 3;
+                        if (c >= nc) { fits = false; break; }
+                        want[(i * 3 + j) * nc + c] += 1.f;
+                    }
+                    if (fits && !memcmp(want, cfh, sizeof(float) * 9 * nc)) pat = q;
+                }
+            }
+            if (P->hub_g == -1) { P->hub_g = I[WF_I_HUB_G]; P->hub_nc = I[WF_I_HUB_NC]; P->hub_pat = pat; }
+            else if (P->hub_g != I[WF_I_HUB_G] || P->hub_nc != I[WF_I_HUB_NC]) P->hub_g = 0;
+            else if (P->hub_pat != pat) P->hub_pat = -1;
+        }
         row0 += T;
     }
     // graphs whose sweep state does not fit the LDS (or, test hook, with at least WF_BIG_MIN_S states): per-frame launches
@@ -3306,8 +3727,11 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         if (P->big && pruned)
             return wf_fail(WF_EUNSUPPORTED, "output_beam pruning is not available for graphs beyond the LDS-resident sweeps (%d states)", P->smax);
         P->pruned = pruned;
-        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok || linbig_config(*P));
-        P->linbig = P->lin && !band_config(*P).ok && !lin_config(*P).ok;
+        const bool hub_ok = hub_config(*P);
+        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok || hub_ok || linbig_config(*P));
+        P->hub = P->lin && !band_config(*P).ok && !lin_config(*P).ok && hub_ok;
+        P->linbig = P->lin && !band_config(*P).ok && !lin_config(*P).ok && !P->hub;
+        if (P->hub) nP = 0;   // no probability arena: the sweep reads log_probs itself
     }
     P->n_E = nE; P->n_ab = nab; P->n_P = nP; P->n_rows = row0;
     size_t o = 0;
@@ -3667,6 +4091,47 @@ bool linbig_config(const Plan& P) {
            linbig_lds(P) <= kLdsBudget;
 }
 
+// hub form (sweep_hub_kernel): every graph of the call, the same (G, NC) instantiation, groups within kHubSlots per
+// compute lane, a probability row within the loader lanes' reach and two of them within the LDS
+size_t hub_kp(const Plan& P) { return align_up((size_t)P.kmax, 64) + 64; }   // a row buffer: whole 64-float DMA pieces
+int hub_nb(const Plan& P) { return 32 * 8 + 32 * 4 + 3 * hub_kp(P) * 4 <= kLdsBudget ? 3 : 2; }
+size_t hub_lds(const Plan& P) { return 32 * 8 + 32 * 4 + (size_t)hub_nb(P) * hub_kp(P) * 4; }
+bool hub_config(const Plan& P) {
+    if (hk().no_hub || hk().no_lin == 1) return false;
+    if (P.hub_g < 2 || P.hub_g > WF_HUB_MAX_G || P.hub_nc < 2 || P.hub_nc > 3 || (P.hub_g == 3 && P.hub_nc != 3)) return false;
+    return P.hub_ng <= kHubSlots * kHubCompute && hub_lds(P) <= kLdsBudget;
+}
+
+template <int G, int NC, int PAT>
+int launch_sweep_hub_one(const Plan& P, SweepArgs a, int B, hipStream_t st) {
+    const size_t lds = hub_lds(P);
+    a.kpad = (int)hub_kp(P);
+    a.chunk = hub_nb(P);
+    a.ablate = hk().sweep_ablate;
+    auto k = sweep_hub_kernel<G, NC, PAT>;
+    { int rc_ = ensure_lds((const void*)k, lds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(k, dim3(B * 2), dim3(kMaxThreads), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+int launch_sweep_hub(const Plan& P, const SweepArgs& a, int B, hipStream_t st) {
+    const int pat = hk().no_hub_pattern ? -1 : P.hub_pat;
+    if (P.hub_g == 2 && P.hub_nc == 2) {
+        if (pat == 0) return launch_sweep_hub_one<2, 2, 0>(P, a, B, st);
+        if (pat == 1) return launch_sweep_hub_one<2, 2, 1>(P, a, B, st);
+        if (pat == 2) return launch_sweep_hub_one<2, 2, 2>(P, a, B, st);
+        if (pat == 3) return launch_sweep_hub_one<2, 2, 3>(P, a, B, st);
+        return launch_sweep_hub_one<2, 2, -1>(P, a, B, st);
+    }
+    if (P.hub_g == 2 && P.hub_nc == 3) {
+        if (pat == 4) return launch_sweep_hub_one<2, 3, 4>(P, a, B, st);
+        return launch_sweep_hub_one<2, 3, -1>(P, a, B, st);
+    }
+    if (P.hub_g == 3 && P.hub_nc == 3) return launch_sweep_hub_one<3, 3, -1>(P, a, B, st);
+    return wf_fail(WF_EUNSUPPORTED, "internal: no hub sweep for G=%d NC=%d", P.hub_g, P.hub_nc);
+}
+
 // rescale bookkeeping of the linear-domain sweep that a call uses: frames per group and lag (lin_shift_index)
 void lin_grp_lag(const Plan& P, int* grp, int* lag) {
     const BandSel bs = band_config(P);
@@ -3804,7 +4269,7 @@ int plan_fb(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, 
     int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, rows ? 0 : 1, P, dbl, pruned);
     if (rc || rows || dbl || P->smax < 4096 || P->big || hk().no_fwd_via_fb) return rc;
     Plan P0;
-    if (make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P0, false, false) == WF_OK && P0.linbig) {
+    if (make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P0, false, false) == WF_OK && (P0.linbig || P0.hub)) {
         *P = P0;
         *fwd_via_fb = true;
     }
@@ -3879,6 +4344,7 @@ int build_seq2utt(const int32_t* seg, int B, int num_seqs, std::vector<int32_t>*
 
 int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                   int64_t strideB, int64_t strideT, hipStream_t st) {
+    if (P.hub) return WF_OK;   // sweep_hub_kernel reads log_probs itself (and clears the fallback flags)
     if (P.lin) {
         GatherLinArgs g{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), lp, strideB, strideT,
                         (float*)(ws + P.off_E), (double*)(ws + P.off_P), (double*)(ws + P.off_cmax),
@@ -3967,6 +4433,24 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     size_t lds = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
     // pre-zeroed rows (some graph compact: the side-stream fill covered the whole box), or only graphs whose columns are the
     // labels (the kernel zeroes the few columns it does not write)
+    if (P.hub && pass != 1) {
+        const dim3 grid(Tmax, num_seqs);
+#define WF_PHUB_CASE(GG, CC) if (P.hub_g == GG && P.hub_nc == CC) hipLaunchKernelGGL((post_hub_kernel<GG, CC>), grid, dim3(256), 0, st, q)
+        WF_PHUB_CASE(2, 2); else WF_PHUB_CASE(2, 3); else WF_PHUB_CASE(3, 3);
+        else return wf_fail(WF_EUNSUPPORTED, "internal: no hub posterior kernel for G=%d NC=%d", P.hub_g, P.hub_nc);
+#undef WF_PHUB_CASE
+        HIP_TRY(hipGetLastError());
+        if (pass == 0) return WF_OK;   // the caller runs the fallback sweep, then this function again with pass = 1
+        q.pass = 1;                    // pass -1: what check_kernel flagged (log-domain rows) is post_big_kernel's
+        hipLaunchKernelGGL(post_big_kernel, grid, dim3(256), 0, st, q);
+        HIP_TRY(hipGetLastError());
+        return WF_OK;
+    }
+    if (P.hub) {   // pass 1
+        hipLaunchKernelGGL(post_big_kernel, dim3(Tmax, num_seqs), dim3(256), 0, st, q);
+        HIP_TRY(hipGetLastError());
+        return WF_OK;
+    }
     if (P.lin && (skip_zero || !P.any_compact) && post_small_fits(P)) {
         q.ecap = (int)align_up(P.kmax, 4);
         q.acap = (int)align_up(P.amax, 4);
@@ -4048,8 +4532,8 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     // workgroups) run; post_kernel then only scatters the K posteriors per row.
     const bool overlap = grad && P.any_compact && !hk().no_overlap;
     // the row check folded into post_small_kernel (no check_kernel launch): when the gradient is computed by this call
-    const bool postcheck = P.lin && grad && !(flags & WF_PREZERO) && (overlap || !P.any_compact) && post_small_fits(P) &&
-                           !hk().no_post_check;
+    const bool postcheck = P.lin && grad && !(flags & WF_PREZERO) && !hk().no_post_check &&
+                           (P.hub || ((overlap || !P.any_compact) && post_small_fits(P)));
     ForkGuard guard(st);   // every return below first makes `st` wait for the side stream
     if ((rc = tm_record(0, st))) return rc;
     rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
@@ -4091,6 +4575,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     a.blob = (const int32_t*)graph_dev; a.utt = (const int64_t*)(ws + P.off_utt);
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT;
     a.E = (const float*)(ws + P.off_E);
+    a.flag_clear = (int32_t*)(ws + P.off_flag); a.cmax_w = (double*)(ws + P.off_cmax);
     a.alpha = ws + P.off_alpha; a.beta = ws + P.off_beta; a.tot = tot; a.bp = nullptr; a.fin_arc = nullptr;
     a.totd = (double*)(ws + P.off_totd);
     a.chunk = c.chunk; a.kpad = c.kpad; a.smax = c.smax; a.arcs_lds_words = c.arcs_words; a.hcap = c.hcap; a.tot_double = 0;
@@ -4108,7 +4593,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
             a.zp = (float4*)grad; a.zn4 = n / 4; a.ztail = grad + (n / 4) * 4; a.zntail = (int)(n - (n / 4) * 4);
             nfill = nfill_sweep;
         }
-        rc = bs.ok ? launch_sweep_band(bs, a, B, st, nfill) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
+        rc = P.hub ? launch_sweep_hub(P, a, B, st) : bs.ok ? launch_sweep_band(bs, a, B, st, nfill) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
         SweepCfg fc = sweep_config_minimal(P, ab);
@@ -4124,10 +4609,19 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
             if (rc) return rc;
             if ((rc = tm_record(4, st))) return rc;
             g_tm.have_post = g_tm.on;
-            RescueArgs r{a.blob, a.utt, (const int32_t*)(ws + P.off_flag), grad_scale, log_probs, strideB, strideT, a.E,
-                         (double*)a.alpha, (double*)a.beta, tot, a.totd, grad};
-            hipLaunchKernelGGL(rescue_kernel, dim3(B), dim3(256), 0, st, r);
-            HIP_TRY(hipGetLastError());
+            if (P.hub) {
+                // a hub state's thousands of arcs are no job for rescue_kernel's one lane per state: the workgroup-wide
+                // fallback sweep and post_big_kernel redo the flagged utterances (both exit at once otherwise)
+                rc = launch_sweep<double, float, M_FB>(fc, fa, B, st);
+                if (rc) return rc;
+                rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st, 1);
+                if (rc) return rc;
+            } else {
+                RescueArgs r{a.blob, a.utt, (const int32_t*)(ws + P.off_flag), grad_scale, log_probs, strideB, strideT, a.E,
+                             (double*)a.alpha, (double*)a.beta, tot, a.totd, grad};
+                hipLaunchKernelGGL(rescue_kernel, dim3(B), dim3(256), 0, st, r);
+                HIP_TRY(hipGetLastError());
+            }
             if ((rc = tm_record(7, st))) return rc;
             g_tm.have_fwd = g_tm.on;
             g_tm.have_check = g_tm.on;
