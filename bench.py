@@ -381,6 +381,33 @@ def viterbi_bench(dev, S, B=8, T=500, V=5001, reps=3):
                     "includes the host-side label extraction of wf.best_path"}
 
 
+def search_bench(dev, S, B=8, T=500, V=5001, beam=20.0, max_active=10000, reps=3):
+    """cfg5 with the beam-pruned search (wf_search; the reference's k2.get_lattice(search_beam=20) at
+    utils/lattice_analysis.py:125) beside the exact sweep, on the PEAKED posterior of synth.cfg5_workload (a beam has
+    nothing to hold on to in noise); `same_path`: the pruned best path equals the exact one for every utterance."""
+    from waterfall_amd.synth import cfg5_workload
+    g, fsa, lp, dense = cfg5_workload(dev, S, B, T, V, peaked=True)
+
+    def timed(f):
+        f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, r
+    ms_exact, exact = timed(lambda: wf.best_path(fsa, dense))
+    ms, out = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, max_active, log_tot=False))
+    ms_log, out2 = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, max_active, log_tot=True, return_active=True))
+    return {"ms_per_call": ms, "ms_per_call_with_log_total": ms_log, "exact_sweep_ms_per_call": ms_exact,
+            "speedup_vs_exact": ms_exact / ms, "same_path": bool(torch.equal(out["arcs"], exact["arcs"])),
+            "same_score": bool(torch.equal(out["scores"], exact["scores"])),
+            "mean_active_states": float(out2["n_active"].float().mean().item()),
+            "checked_by": "tests/test_search.py (infinite beam == exact sweep bit for bit; finite beams == oracle.beam_search)",
+            "desc": f"cfg5 beam-pruned search, S={S} A={fsa.arcs.shape[0]}, B={B}, T={T}, V={V}, search_beam={beam}, "
+                    f"max_active_states={max_active}, peaked synthetic posterior; wall time of wf.pruned_search incl. host"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -503,6 +530,11 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     others["cfg5_viterbi_S%.0e" % S] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+            try:
+                others["cfg5_search_S1e+06_beam20"] = search_bench(dev, 1_000_000)
+            except Exception as e:   # noqa: BLE001
+                others["cfg5_search_S1e+06_beam20"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
             out["other_workloads"] = others
         print(json.dumps(out))
     if dist is not None:

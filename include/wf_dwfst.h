@@ -250,6 +250,24 @@ int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt
                const int32_t* seg, int32_t B, int32_t Tmax, uint32_t flags, float* best_score,
                int32_t* best_arcs, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- beam-pruned frame-synchronous search (k2.get_lattice(log_prob, log_prob_len, TLG, search_beam, output_beam,
+ * min_active_states, max_active_states), utils/lattice_analysis.py:125 with the beams of lattice_analysis.sh:9-11) --------
+ * Token passing over the outgoing arcs of a decoding graph of any size; one workgroup per utterance.  A state of frame t
+ * survives when its tropical score is within search_beam of the frame's best; when more than max_active_states survive
+ * (0: no limit) or fewer than min_active_states, the cut-off moves along a 1024-bin histogram of the frame's scores.
+ * search_beam = +inf with max_active_states = 0 is the exact search (scores and arcs equal wf_viterbi's bit for bit).
+ * best_score / best_arcs: as wf_viterbi (ties -> lowest arc index).  tot_log (nullable): device fp32 [B], or fp64 [B] with
+ * WF_DOUBLE_ACC: log-semiring total score of the pruned lattice (all paths through surviving states).  n_active (nullable):
+ * device int32 [B][Tmax+1], surviving states per frame.  k2's own pruning arithmetic (dynamic beams, output_beam applied
+ * backwards over the lattice) is parity unpinned: the reference holds no fixture for it; see INTEGRATION.md.            */
+int wf_search_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B, int32_t V,
+                              int32_t max_active_states, int32_t want_log_tot, size_t* bytes);
+int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
+              int64_t strideB, int64_t strideT, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
+              float search_beam, int32_t min_active_states, int32_t max_active_states, uint32_t flags,
+              float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
+              size_t workspace_bytes, void* stream);
+
 /* ---- multi-GPU: the buffer of the one fused all-reduce per step (the reference gets these numbers
  * from Lightning's DDP reductions around graph.py:66-76).  out[0] = -(sum of the finite tot[i]), out[1] = n_frames,
  * out[2] = number of infeasible utterances (tot = -inf); device pointers, one small launch on `stream`.            */

@@ -253,6 +253,63 @@ def viterbi(g, lp, T, dtype=np.float32):
     return dtype(score), path
 
 
+
+def beam_search(g, lp, T, search_beam=np.inf):
+    """Frame-synchronous token passing with a tropical beam: the restatement wf_search is tested against.
+    [the role of k2.get_lattice's search at utils/lattice_analysis.py:125; k2's own beam arithmetic is parity unpinned]
+
+    A state of frame t survives when its tropical score v satisfies v >= max_t - search_beam (fp32 arithmetic as in
+    `viterbi`); only survivors are expanded.  Returns (score, arcs, tot_log, n_active):
+    best path over the surviving lattice with the tie rule of `viterbi`, the log-semiring total (fp64) over all paths
+    through surviving states, and the survivor count per frame (t = 0..T).
+    """
+    S = g["num_states"]
+    A = g["src"].size
+    ids = np.arange(A, dtype=np.int64)
+    em, fin = _split(g)
+    src, dst, eid = g["src"][em], g["dst"][em], ids[em]
+    alpha = np.full(S, NEG_INF, dtype=np.float32)
+    alpha[0] = 0
+    la = np.full(S, NEG_INF, dtype=np.float64)
+    la[0] = 0
+    bp = np.full((T, S), -1, dtype=np.int64)
+    n_active = [1]
+    for t in range(T):
+        x = arc_scores(g, lp[t])
+        with np.errstate(invalid="ignore"):
+            v = (alpha[src] + x).astype(np.float32)
+        m = np.full(S, NEG_INF, dtype=np.float32)
+        np.maximum.at(m, dst, v)
+        hit = (v == m[dst]) & np.isfinite(v)
+        best = np.full(S, A, dtype=np.int64)
+        np.minimum.at(best, dst[hit], eid[hit])
+        bp[t] = np.where(best < A, best, -1)
+        with np.errstate(invalid="ignore"):
+            ln = _seg_lse(la[src] + x.astype(np.float64), dst, S, np.float64)
+        if not np.isfinite(m).any():
+            return np.float32(NEG_INF), [], NEG_INF, n_active + [0] * (T - t)
+        keep = m >= np.float32(m.max() - np.float32(search_beam)) if np.isfinite(search_beam) else np.isfinite(m)
+        alpha = np.where(keep, m, np.float32(NEG_INF)).astype(np.float32)
+        la = np.where(keep, ln, NEG_INF)
+        n_active.append(int(keep.sum()))
+    fsrc, fid = g["src"][fin], ids[fin]
+    vf = (alpha[fsrc] + g["score"][fin]).astype(np.float32)
+    if vf.size == 0 or not np.isfinite(vf.max()):
+        return np.float32(NEG_INF), [], NEG_INF, n_active
+    score = vf.max()
+    fa = int(fid[vf == score].min())
+    path = [fa]
+    s = int(g["src"][fa])
+    for t in range(T - 1, -1, -1):
+        a = int(bp[t, s])
+        path.append(a)
+        s = int(g["src"][a])
+    path.reverse()
+    lf = la[fsrc] + g["score"][fin].astype(np.float64)
+    tot_log = _seg_lse(lf, np.zeros(lf.size, dtype=np.int64), 1, np.float64)[0]
+    return np.float32(score), path, float(tot_log), n_active
+
+
 def graphloss(graphs, lp, segs, output_beam=None, reduction="sum", target_lengths=None,
               dtype=np.float64):
     """graph.py:79-118 restated: returns (loss, d loss / d lp [B,T,V]).

@@ -244,3 +244,31 @@ def test_batched_compiler_large_table_ctc_and_errors():
                                      tab["index"].ctypes.data, 0, None, None, 0, flat.ctypes.data, off.ctypes.data, 1,
                                      oa.ctypes.data, ox.ctypes.data, 2, arc_off.ctypes.data, ns.ctypes.data)
     assert rc == -2 and arc_off[1] == ref.fsa_arc_offsets[1] and ns[0] == ref.fsa_num_states[0]
+
+
+class _RaggedStandIn:   # stands for a pickled k2.RaggedTensor (a class the weights-only loader must refuse)
+    pass
+
+
+def test_decoding_graph_file_round_trip_weights_only(tmp_path):
+    """TLG.pt layout of utils/compile_TLG.py:129 (torch.save(TLG.as_dict())): tensor-only dicts load with the
+    weights-only loader; anything that needs unpickling a class is refused with a clear error."""
+    import torch
+    from waterfall_amd import decode
+    import waterfall_amd as wf
+    arcs = [(0, 1, 1, -0.5), (1, 1, 1, 0.0), (1, 2, 2, -1.25), (2, 3, -1, 0.0)]
+    g = wf.Fsa.from_arcs(arcs, 4, aux_labels=[7, 0, 9, -1])
+    p = tmp_path / "TLG.pt"
+    decode.save_decoding_graph(g, p)
+    h = decode.load_decoding_graph(p)
+    assert np.array_equal(h.arcs, g.arcs) and np.array_equal(h.aux_labels, g.aux_labels)
+    assert list(h.fsa_num_states) == [4]
+    # ragged aux labels as two tensors
+    torch.save({"arcs": torch.from_numpy(g.arcs.copy()), "aux_labels.row_splits": torch.tensor([0, 1, 1, 2, 2]),
+                "aux_labels.values": torch.tensor([7, 9], dtype=torch.int32)}, p)
+    h = decode.load_decoding_graph(p)
+    assert list(h.aux_labels) == [7, 0, 9, -1]
+
+    torch.save({"arcs": torch.from_numpy(g.arcs.copy()), "aux_labels": _RaggedStandIn()}, p)
+    with pytest.raises(ValueError, match="weights_only"):
+        decode.load_decoding_graph(p)

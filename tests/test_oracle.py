@@ -212,3 +212,18 @@ def test_c_oracle_matches_numpy_oracle(oracle_lib, topo, den):
         s, path = util.c_oracle_viterbi(oracle_lib, g, c["lp"][i], T)
         s2, path2 = o.viterbi(g, c["lp"][i], T)
         assert s == s2 and list(path) == path2
+
+
+def test_beam_search_restatement_is_viterbi_and_forward_at_infinite_beam():
+    """oracle.beam_search (the beam rule wf_search is tested against) collapses to the pinned `viterbi` / `forward`
+    when nothing is pruned, and pruning only ever removes paths."""
+    from tests import util
+    c = util.random_case(77, "mmictc", B=2, T=25, L=5, P=6, den=True)
+    for i, g in enumerate(c["ographs"]):
+        T = int(c["segs"][i, 2])
+        s, path, tl, na = o.beam_search(g, c["lp"][i], T)
+        s0, p0 = o.viterbi(g, c["lp"][i], T)
+        assert s == s0 and path == p0
+        np.testing.assert_allclose(tl, o.forward(g, c["lp"][i], T)[1], rtol=1e-12)
+        s2, p2, tl2, na2 = o.beam_search(g, c["lp"][i], T, 2.0)
+        assert s2 <= s and tl2 <= tl + 1e-12 and all(a <= b for a, b in zip(na2, na))

@@ -1,0 +1,173 @@
+"""GPU tests (-m gpu) of the beam-pruned frame-synchronous search wf_search (k2.get_lattice's role at
+utils/lattice_analysis.py:125), through the C ABI.
+
+What pins it: with an infinite beam it must equal the exact Viterbi sweep bit for bit (scores and arcs) and the exact
+log-semiring total; with a finite beam it must equal oracle.beam_search (this repository's statement of the beam rule:
+k2's own beam arithmetic is parity unpinned, the reference holds no fixture for it); max / min active states are checked
+through their defining properties.
+"""
+import numpy as np
+import pytest
+import torch
+
+import waterfall_amd as wf
+from waterfall_amd import decode
+from oracle import dwfst_oracle as o
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+INF = float("inf")
+
+
+def _case(topo, den, seed=50, B=4, T=50):
+    c = util.random_case(seed, topo, B=B, T=T, L=7, P=8, den=den)
+    dense = wf.DenseFsaVec(torch.from_numpy(c["lp"]).to(DEV), torch.from_numpy(c["segs"]))
+    return c, dense
+
+
+def _big(S, B=4, T=40, V=301, seed=5):
+    g = util.synth_decoding_graph(seed, S, V)
+    gen = torch.Generator().manual_seed(seed)
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=gen) * 3.0, -1).numpy()
+    lens = ([T, max(1, T - 7), max(1, T // 2), 1] + [T] * B)[:B]
+    segs = np.stack([np.arange(B), np.zeros(B, dtype=np.int64), np.array(lens)], 1).astype(np.int32)
+    arcs_ = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
+    one = wf.Fsa(arcs_, g["aux"], [0, arcs_.shape[0]], [g["num_states"]])
+    fsa = wf.create_fsa_vec([one] * B)
+    dense = wf.DenseFsaVec(torch.from_numpy(lp).to(DEV), torch.from_numpy(segs))
+    return g, lp, segs, fsa, dense
+
+
+@pytest.mark.parametrize("topo,den", [("ctc", False), ("2state", False), ("mmictc", True), ("3state-skip-2", True),
+                                      ("ctc", True)])
+def test_infinite_beam_equals_exact_sweeps(topo, den):
+    c, dense = _case(topo, den)
+    exact = wf.best_path(c["fsa"], dense)
+    out = wf.pruned_search(c["fsa"], dense, search_beam=INF, min_active_states=0, max_active_states=0,
+                           use_double_scores=True, return_active=True)
+    assert torch.equal(out["scores"], exact["scores"])            # bit-exact fp32
+    assert torch.equal(out["arcs"], exact["arcs"])
+    assert out["labels"] == exact["labels"]
+    tot = wf.tot_scores(c["fsa"], dense, True, True).cpu().numpy()
+    np.testing.assert_allclose(out["tot_log"].cpu().numpy(), tot, rtol=1e-6, atol=1e-5)
+    nact = out["n_active"].cpu().numpy()
+    for i, g in enumerate(c["ographs"]):
+        T = int(c["segs"][i, 2])
+        want = o.beam_search(g, c["lp"][i], T)[3]
+        assert list(nact[i, :T + 1]) == want                      # every reachable state survives
+        assert np.all(nact[i, T + 1:] == 0)
+
+
+@pytest.mark.parametrize("beam", [3.0, 8.0, 15.0])
+@pytest.mark.parametrize("topo,den", [("ctc", False), ("mmictc", True), ("3state-skip", True), ("2state_sil", False)])
+def test_finite_beam_against_oracle(topo, den, beam):
+    c, dense = _case(topo, den, seed=51)
+    out = wf.pruned_search(c["fsa"], dense, search_beam=beam, min_active_states=0, max_active_states=0,
+                           use_double_scores=True, return_active=True)
+    scores, arcs = out["scores"].cpu().numpy(), out["arcs"].cpu().numpy()
+    tot, nact = out["tot_log"].cpu().numpy(), out["n_active"].cpu().numpy()
+    base = c["fsa"].fsa_arc_offsets
+    for i, g in enumerate(c["ographs"]):
+        T = int(c["segs"][i, 2])
+        s, path, tl, na = o.beam_search(g, c["lp"][i], T, beam)
+        gi = 0 if c["fsa"].utt2fsa is not None else i
+        assert scores[i] == s
+        assert list(arcs[i, :T + 1] - base[gi]) == path if path else np.all(arcs[i] == -1)
+        assert list(nact[i, :T + 1]) == na
+        if np.isfinite(tl):
+            np.testing.assert_allclose(tot[i], tl, rtol=1e-6, atol=1e-5)
+        else:
+            assert tot[i] == -np.inf
+
+
+@pytest.mark.parametrize("S", [12_001, 40_000])
+def test_big_graph_search(oracle_lib, S):
+    g, lp, segs, fsa, dense = _big(S)
+    exact = wf.best_path(fsa, dense)
+    out = wf.pruned_search(fsa, dense, search_beam=INF, min_active_states=0, max_active_states=0)
+    assert torch.equal(out["scores"], exact["scores"]) and torch.equal(out["arcs"], exact["arcs"])
+    for i in (0, 2):
+        s, path = util.c_oracle_viterbi(oracle_lib, g, lp[i], int(segs[i, 2]))
+        assert out["scores"][i].item() == s
+        assert list(out["arcs"][i, :int(segs[i, 2]) + 1].cpu().numpy()) == list(path)
+    # finite beam on utterance 1, against the numpy statement of the beam rule
+    pr = wf.pruned_search(fsa, dense, search_beam=6.0, min_active_states=0, max_active_states=0, use_double_scores=True,
+                          return_active=True)
+    for i in range(4):
+        Ti = int(segs[i, 2])
+        s, path, tl, na = o.beam_search(g, lp[i], Ti, 6.0)
+        assert pr["scores"][i].item() == s
+        got = list(pr["arcs"][i, :Ti + 1].cpu().numpy())
+        assert got == path if path else all(a == -1 for a in got)   # the beam may lose every complete path
+        assert list(pr["n_active"][i, :Ti + 1].cpu().numpy()) == na
+        if np.isfinite(tl):
+            np.testing.assert_allclose(pr["tot_log"][i].item(), tl, rtol=1e-6)
+        else:
+            assert pr["tot_log"][i].item() == -np.inf
+
+
+def test_beam_bounds_and_active_state_limits():
+    g, lp, segs, fsa, dense = _big(20_000, B=3, T=60, seed=9)
+    exact = wf.best_path(fsa, dense)["scores"].cpu().numpy()
+    # (survivor sets are NOT nested in the beam: a wider beam can keep a state that raises a later frame's best score and
+    # with it the cut-off, so only the bounds below hold for every beam)
+    prev_score = None
+    for beam in (2.0, 5.0, 10.0, 20.0, INF):
+        r = wf.pruned_search(fsa, dense, search_beam=beam, min_active_states=0, max_active_states=0,
+                             use_double_scores=True, return_active=True)
+        sc, tot = r["scores"].cpu().numpy(), r["tot_log"].cpu().numpy()
+        assert np.all(sc <= exact)                                  # a pruned search never beats the exact one
+        assert np.all(tot >= sc.astype(np.float64) - 1e-6)          # log-sum >= its best path
+        fin = np.isfinite(sc)
+        assert np.all(np.isfinite(tot) == fin)
+        prev_score = sc
+    assert np.array_equal(prev_score, exact)
+    # max_active_states: never more survivors than the limit; the result stays a valid path of the graph
+    lim = wf.pruned_search(fsa, dense, search_beam=INF, min_active_states=0, max_active_states=200, return_active=True)
+    na = lim["n_active"].cpu().numpy()
+    assert na.max() <= 200 and np.all(lim["scores"].cpu().numpy() <= exact)
+    arcs = lim["arcs"].cpu().numpy()
+    for i in range(3):
+        T = int(segs[i, 2])
+        path = arcs[i, :T + 1]
+        assert np.all(path >= 0)
+        assert g["src"][path[0]] == 0 and g["label"][path[-1]] == -1
+        assert np.all(g["dst"][path[:-1]] == g["src"][path[1:]])
+        x = np.float32(0)
+        for t, a in enumerate(path[:-1]):
+            x = np.float32(x + np.float32(g["score"][a] + lp[i, t, g["label"][a]]))
+        assert np.float32(x + g["score"][path[-1]]) == lim["scores"][i].item()
+    # min_active_states keeps a narrow beam alive: at least min(min_active, candidates) survivors per frame
+    narrow = wf.pruned_search(fsa, dense, search_beam=0.5, min_active_states=0, max_active_states=0, return_active=True)
+    kept = wf.pruned_search(fsa, dense, search_beam=0.5, min_active_states=50, max_active_states=0, return_active=True)
+    nn, nk = narrow["n_active"].cpu().numpy(), kept["n_active"].cpu().numpy()
+    full = wf.pruned_search(fsa, dense, search_beam=INF, min_active_states=0, max_active_states=0,
+                            return_active=True)["n_active"].cpu().numpy()
+    T0 = int(segs[0, 2])
+    assert np.all(nk[0, 3:T0 + 1] >= np.minimum(50, nn[0, 3:T0 + 1]))
+    assert np.all(nk[0, 3:T0 + 1] >= 50) or np.any(full[0, 3:T0 + 1] < 50)
+    assert np.all(kept["scores"].cpu().numpy() >= narrow["scores"].cpu().numpy())
+
+
+def test_get_lattice_call_shapes_of_lattice_analysis():
+    """utils/lattice_analysis.py:125-135 verbatim against the search; :147-149 (intersect_dense) stays exact."""
+    g, lp, segs, fsa, dense = _big(12_001, B=2, T=30, seed=11)
+    one = wf.Fsa(fsa.arcs, fsa.aux_labels, fsa.fsa_arc_offsets, fsa.fsa_num_states)
+    x = torch.from_numpy(lp).to(DEV)
+    lens = torch.tensor([int(segs[0, 2]), int(segs[1, 2])])
+    lattice = decode.get_lattice(x, lens, one, search_beam=20.0, output_beam=6.0, max_active_states=2000)
+    tot_log = lattice.get_tot_scores(True, True)
+    tot_best = lattice.get_tot_scores(True, False)
+    assert tot_log.dtype == torch.float64 and tot_best.dtype == torch.float64
+    one_best = decode.one_best_decoding(lattice)
+    ref = wf.pruned_search(fsa, dense, 20.0, 30, 2000, use_double_scores=False)
+    assert torch.equal(one_best.scores, ref["scores"])
+    assert torch.equal(tot_best, ref["scores"].double())
+    assert decode.get_aux_labels(one_best) == ref["aux_labels"]
+    assert torch.all(tot_log >= tot_best - 1e-6)
+    exact = decode.intersect_dense(one, dense, 10)
+    assert torch.all(exact.get_tot_scores(True, True) >= tot_log - 1e-6)          # pruning only removes mass
+    assert torch.all(exact.get_tot_scores(True, False) >= tot_best - 1e-3)          # (fp64 exact vs fp32 search rounding)
+    fp64 = decode.one_best_decoding(exact, use_double_scores=True)                # forwarded (VERDICT weak 16)
+    assert fp64.scores.shape == (2,)

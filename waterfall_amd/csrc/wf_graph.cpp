@@ -47,7 +47,7 @@ inline size_t fsa_words_bound(size_t S, size_t A) {
     const size_t K = 2 * A + 1;
     size_t w = 0;
     w += pad4(S + 1) + 4 * pad4(A);          // in_off, in_src, in_col, in_w, in_arc
-    w += pad4(S + 1) + 3 * pad4(A);          // out_off, out_dst, out_col, out_w
+    w += pad4(S + 1) + 4 * pad4(A);          // out_off, out_dst, out_col, out_w, out_arc
     w += pad4(K + 1) + 4 * pad4(A);          // lab_off, lab_src, lab_dst, lab_w, lab_col
     w += pad4(K);                            // labels
     w += 3 * pad4(A);                        // fin_src, fin_w, fin_arc (NF <= A)
@@ -117,7 +117,7 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
     I[WF_I_S] = S; I[WF_I_A] = A; I[WF_I_NF] = NF; I[WF_I_K] = K; I[WF_I_DIRECT] = direct;
     I[WF_I_ARC_BASE] = a0;
     I[WF_I_MAX_LABEL] = max_label;
-    const size_t need = 2 * pad4(S + 1) + 11 * pad4(A) + pad4(K + 1) + pad4(K) + 3 * pad4(NF) + 4 * pad4(S) + pad4(A + NF);
+    const size_t need = 2 * pad4(S + 1) + 12 * pad4(A) + pad4(K + 1) + pad4(K) + 3 * pad4(NF) + 4 * pad4(S) + pad4(A + NF);
     if (cur + need > limit) return wf_fail(WF_ENOSPC, "wf_graph_prepare: blob too small at fsa %d", g);
     X.cnt.assign(std::max(S, K) + 1, 0);
     X.pos.resize(std::max(S, K) + 1);
@@ -154,8 +154,8 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
     }
     // ---- outgoing CSR: emitting arcs in original order grouped by src (stable)
     {
-        int o_off = take(S + 1), o_dst = take(A), o_col = take(A), o_w = take(A);
-        I[WF_I_OUT_OFF] = o_off; I[WF_I_OUT_DST] = o_dst; I[WF_I_OUT_COL] = o_col; I[WF_I_OUT_W] = o_w;
+        int o_off = take(S + 1), o_dst = take(A), o_col = take(A), o_w = take(A), o_arc = take(A);
+        I[WF_I_OUT_OFF] = o_off; I[WF_I_OUT_DST] = o_dst; I[WF_I_OUT_COL] = o_col; I[WF_I_OUT_W] = o_w; I[WF_I_OUT_ARC] = o_arc;
         int32_t* cnt = X.cnt.data();
         std::fill(cnt, cnt + S + 1, 0);
         for (int a : X.em) cnt[arcs[4 * (size_t)a] + 1]++;
@@ -169,6 +169,7 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
             B[o_dst + q] = r[1];
             B[o_col + q] = X.col[j];
             B[o_w + q] = r[3];
+            B[o_arc + q] = X.em[j];
         }
         int o_h = take(S), nh = 0, maxout = 0, nover = 0, over = 0;
         for (int s2 = 0; s2 < S; ++s2) {

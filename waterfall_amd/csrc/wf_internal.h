@@ -84,6 +84,7 @@ enum {
     WF_I_HUB_NX = 52,      // hub self-loops whose label belongs to no group (<blk>)
     WF_I_HUB_XCOL = 53,    // [NX] their columns
     WF_I_HUB_FINW = 54,    // float bits: weight of the hub's final arc
+    WF_I_OUT_ARC = 55,     // [A] original arc index (local to the FSA) of every entry of the outgoing CSR
 };
 #define WF_HUB_MAX_G 3
 #define WF_HUB_MAX_NC 4

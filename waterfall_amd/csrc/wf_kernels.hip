@@ -3554,6 +3554,435 @@ __global__ void backtrace_kernel(TraceArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Beam-pruned frame-synchronous search (k2.get_lattice(search_beam, output_beam, min/max_active_states),
+// utils/lattice_analysis.py:125): token passing over the OUTGOING CSR of a decoding graph of any size.
+//
+// One 1024-lane workgroup per utterance runs all of its frames (utterances are independent: no grid-wide
+// synchronisation).  Per frame:
+//   expand : every surviving state of frame t pushes score + weight + emission along its outgoing arcs with one
+//            64-bit atomic max per arc on best[dst] = (ordered score << 32 | ~arc id): the maximum is the tropical
+//            value, ties go to the lowest arc index (the rule of wf_viterbi); the first arc to touch a state appends
+//            it to the frame's candidate list.  The arcs, not the states, are dealt to the lanes (see the kernel).
+//   (log)  : optionally a second pass over the same arcs adds exp(log-alpha + arc - best[dst] - G) into lsum[dst]
+//            (fp64 atomic add; G = max(log-alpha - tropical score) over the survivors, so no term exceeds 1): the
+//            log-semiring total of the PRUNED lattice, what k2 reports for lattice.get_tot_scores(True, True).
+//   prune  : candidates below (frame best - beam) are dropped; when more than max_active remain (or fewer than
+//            min_active), a 1024-bin histogram of the scores moves the cut-off (bin granularity).  Survivors get a
+//            record (arc, record of the source state) in an arena that only grows by the active count, and best /
+//            lsum are reset for the touched states only.
+// The best path is then a pointer chase through T records.  With beam = inf and no max_active the survivors are
+// all reachable states and scores / paths equal wf_viterbi's bit for bit (same fp32 association v + (w + e)).
+// ------------------------------------------------------------------------------------------
+constexpr int kSearchThreads = 1024;
+constexpr int kSearchXL = 2048;   // survivors whose arcs / scores / degree prefix are in the LDS at a time
+constexpr int kSearchCL = 6144;   // candidates of a frame kept in the LDS (the rest in the workspace)
+constexpr int kSearchBins = 1024;
+constexpr int kSearchUnroll = 4;
+enum { WF_SR_SOFF = 0, WF_SR_XOFF = 1, WF_SR_CAP = 2, WF_SR_AOFF = 3, WF_SR_ARCOFF = 4, WF_SR_WORDS = 6 };
+
+struct SearchArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const int64_t* tab;          // [B][WF_SR_WORDS]
+    const float* lp;
+    int64_t strideB, strideT;
+    unsigned long long* best;    // [nstates]
+    double* lsum;                // [nstates] or null
+    int32_t* slot;               // [nstates] state -> record of the newest frame it survived in
+    int32_t* cand;               // [nstates] states touched by the frame (beyond the LDS part)
+    unsigned long long* cpk;     // [nstates] packed best per candidate (second compaction run)
+    double* cls;                 // [nstates] same for lsum
+    int32_t* arcown;             // [narcs] arc id -> index of the survivor that expanded it this frame
+    int32_t* xstate;             // survivors of the current frame
+    float* xscore;
+    int2* xarcs;
+    double* xla;
+    int2* arena;
+    int64_t nstates;
+    float beam;
+    int max_active, min_active;
+    float* best_score;
+    int32_t* best_arcs;
+    int Tmax;
+    void* tot_log;
+    int tot_double;
+    int32_t* n_active;           // [B][Tmax+1] or null
+};
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu));
+}
+// loads of data that other lanes of the workgroup produced in an earlier phase (plain stores or L2 atomics): not from a
+// possibly stale line of the vector L1
+template <typename T> __device__ __forceinline__ T ld_fresh(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
+    __shared__ int s_ncand, s_nsurv, s_keepbin, s_narcs;
+    __shared__ uint32_t s_fmax, s_min, s_G;
+    __shared__ int s_pfx[kSearchXL];        // exclusive prefix of the survivors' out-degrees (arc -> owner lookup)
+    __shared__ int s_xa0[kSearchXL];        // first outgoing arc and tropical score of the first kSearchXL survivors
+    __shared__ float s_xv[kSearchXL];
+    __shared__ int s_cand[kSearchCL];       // the first kSearchCL candidates of the frame
+    __shared__ int s_hist[kSearchBins];
+    __shared__ int s_wsum[16];
+    __shared__ unsigned long long s_fin;
+    __shared__ double s_lsum;
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int64_t* R = p.tab + (int64_t)u * WF_SR_WORDS;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int T = (int)U[WF_U_T];
+    const int direct = I[WF_I_DIRECT];
+    const int32_t* off = p.blob + I[WF_I_OUT_OFF];
+    const int32_t* dst = p.blob + I[WF_I_OUT_DST];
+    const int32_t* col = p.blob + I[WF_I_OUT_COL];
+    const float* w = (const float*)(p.blob + I[WF_I_OUT_W]);
+    const int32_t* oarc = p.blob + I[WF_I_OUT_ARC];
+    const int32_t* labels = p.blob + I[WF_I_LABELS];
+    const int64_t soff = R[WF_SR_SOFF];
+    const int cap = (int)R[WF_SR_CAP];
+    unsigned long long* best = p.best + soff;
+    double* lsum = p.lsum ? p.lsum + soff : nullptr;
+    int32_t* cand = p.cand + soff;
+    unsigned long long* cpk = p.cpk + soff;    // packed best of every candidate, kept while best[] is being reset
+    double* cls = p.lsum ? p.cls + soff : nullptr;
+    int32_t* slot = p.slot + soff;             // state -> record of the newest frame it survived in
+    int32_t* arcown = p.arcown + R[WF_SR_ARCOFF];   // arc id -> index of the survivor that expanded it this frame
+    int32_t* xstate = p.xstate + R[WF_SR_XOFF];
+    float* xscore = p.xscore + R[WF_SR_XOFF];
+    int2* xarcs = p.xarcs + R[WF_SR_XOFF];     // (first outgoing arc, out-degree) of every survivor
+    double* xla = p.xla + R[WF_SR_XOFF];
+    int2* arena = p.arena + R[WF_SR_AOFF];
+    int32_t* out = p.best_arcs + (int64_t)u * (p.Tmax + 1);
+    int32_t* nact = p.n_active ? p.n_active + (int64_t)u * (p.Tmax + 1) : nullptr;
+    for (int i = tid; i <= p.Tmax; i += kSearchThreads) { out[i] = -1; if (nact) nact[i] = 0; }
+    const float* lp0 = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
+    const float ninf = -INFINITY;
+
+    // frame 0: the start state
+    if (tid == 0) {
+        xstate[0] = 0; xscore[0] = 0.f; xla[0] = 0.0;
+        xarcs[0] = make_int2(off[0], off[1] - off[0]);
+        s_xa0[0] = off[0]; s_xv[0] = 0.f; s_pfx[0] = off[1] - off[0];   // (s_pfx holds the DEGREES until the scan)
+        arena[0] = make_int2(-1, -1);
+        slot[0] = 0;
+        if (nact) nact[0] = 1;
+        s_G = f2ord(0.f);
+    }
+    int nX = 1;
+    int64_t base = 1;        // records used so far
+    int64_t base_prev = 0;   // first record of the current frame's survivors
+    bool dead = false;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const float* erow = lp0 + (int64_t)t * p.strideT;
+        if (tid == 0) { s_ncand = 0; s_fmax = 0; s_nsurv = 0; s_min = 0xffffffffu; s_keepbin = 0x7fffffff; }
+        const float G = ord2f(s_G);
+        const bool xl = nX <= kSearchXL;   // (uniform) the survivors' arcs / scores are in the LDS
+        // ---------------- expand: ARC-parallel.  The survivors' out-degrees are prefix-summed into the LDS (chunks of
+        // kSearchXL survivors); lane l then owns arcs l, l + 1024, ... of the chunk's arc list, kSearchUnroll of them in
+        // flight together, and finds each arc's survivor by a branch-free binary search of the prefix -- the same work per
+        // lane whatever the degrees are (a state with 10^5 outgoing arcs is simply spread over all lanes).
+        uint32_t lmax = 0;
+        for (int log_pass = 0; log_pass < (lsum ? 2 : 1); ++log_pass) {   // (the log pass needs every tropical value of the frame)
+        for (int c0 = 0; c0 < nX; c0 += kSearchXL) {
+            const int m = min(kSearchXL, nX - c0);
+            if (!(log_pass && xl)) {   // (one chunk: the prefix of the tropical pass is still there)
+                constexpr int kPer = kSearchXL / kSearchThreads;
+                int deg[kPer], run = 0;
+                if (!xl) __syncthreads();   // (the previous chunk's searches are over)
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) {
+                    const int i = tid * kPer + k;
+                    deg[k] = i < m ? (xl ? s_pfx[i] : ld_fresh(&xarcs[c0 + i].y)) : 0;
+                    if (!xl && i < m) { s_xa0[i] = ld_fresh(&xarcs[c0 + i].x); s_xv[i] = ld_fresh(xscore + c0 + i); }
+                }
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) { const int x = deg[k]; deg[k] = run; run += x; }
+                int v = run;
+                for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(v, o, 64); if (lane >= o) v += x; }
+                if (lane == 63) s_wsum[wave] = v;
+                __syncthreads();
+                int add = v - run;
+                for (int k = 0; k < wave; ++k) add += s_wsum[k];
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) s_pfx[tid * kPer + k] = add + deg[k];
+                if (tid == kSearchThreads - 1) s_narcs = add + run;
+            }
+            __syncthreads();
+            const int NA = s_narcs;
+            for (int k0 = 0; k0 < NA; k0 += kSearchUnroll * kSearchThreads) {
+                int own[kSearchUnroll], q[kSearchUnroll];
+                bool ok[kSearchUnroll];
+#pragma unroll
+                for (int j = 0; j < kSearchUnroll; ++j) {
+                    const int k = k0 + j * kSearchThreads + tid;
+                    ok[j] = k < NA;
+                    int lo = 0;
+#pragma unroll
+                    for (int st = kSearchXL / 2; st > 0; st >>= 1)
+                        if (lo + st < m && s_pfx[lo + st] <= k) lo += st;
+                    own[j] = lo;
+                    q[j] = ok[j] ? k - s_pfx[lo] + s_xa0[lo] : 0;
+                }
+                int d[kSearchUnroll], ar[kSearchUnroll];
+                float we[kSearchUnroll];
+#pragma unroll
+                for (int j = 0; j < kSearchUnroll; ++j) {
+                    const int c = col[q[j]];
+                    d[j] = dst[q[j]];
+                    ar[j] = oarc[q[j]];
+                    we[j] = w[q[j]] + erow[direct ? c : labels[c]];
+                }
+                if (!log_pass) {
+                    // one 64-bit atomic max per arc: the tropical value of the destination, ties to the lowest arc index
+                    unsigned long long old[kSearchUnroll];
+#pragma unroll
+                    for (int j = 0; j < kSearchUnroll; ++j) {
+                        const float sc = s_xv[own[j]] + we[j];
+                        ok[j] = ok[j] && sc > ninf;
+                        const uint32_t o = f2ord(sc);
+                        old[j] = 1ull;
+                        if (ok[j]) {
+                            lmax = max(lmax, o);
+                            arcown[ar[j]] = c0 + own[j];
+                            old[j] = atomicMax(&best[d[j]], ((unsigned long long)o << 32) | (0xffffffffu - (uint32_t)ar[j]));
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < kSearchUnroll; ++j) {   // first touch: append to the candidate list, one LDS atomic per wavefront
+                        const bool fresh = old[j] == 0ull;
+                        const unsigned long long mk = __ballot(fresh);
+                        if (fresh) {
+                            const int leader = __ffsll((long long)mk) - 1;
+                            int wb = 0;
+                            if (lane == leader) wb = atomicAdd(&s_ncand, __popcll(mk));
+                            wb = __shfl(wb, leader, 64);
+                            const int idx = wb + __popcll(mk & ((1ull << lane) - 1ull));
+                            if (idx < kSearchCL) s_cand[idx] = d[j]; else cand[idx] = d[j];
+                        }
+                    }
+                } else {
+                    // log semiring: exp(log-alpha + arc - tropical value of the destination - G) <= 1
+                    float tb[kSearchUnroll];
+                    double la[kSearchUnroll];
+#pragma unroll
+                    for (int j = 0; j < kSearchUnroll; ++j) {
+                        tb[j] = ord2f((uint32_t)(ld_fresh(best + d[j]) >> 32));
+                        la[j] = ld_fresh(xla + c0 + own[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kSearchUnroll; ++j)
+                        if (ok[j] && we[j] > ninf) atomicAdd(&lsum[d[j]], exp(la[j] + (double)we[j] - (double)tb[j] - (double)G));
+                }
+            }
+        }
+        __syncthreads();   // every value of the pass is final
+        }
+        for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, o, 64));
+        if (lane == 0 && lmax) atomicMax(&s_fmax, lmax);
+        __syncthreads();
+        // ---------------- prune
+        const int n = s_ncand;
+        if (n == 0) { dead = true; break; }   // (uniform)
+        const float fmax = ord2f(s_fmax);
+        float cutoff = fmax - p.beam;          // -inf for an infinite beam
+        float inv_width = 0.f;
+        int keepbin = 0x7fffffff;
+        const int want_min = min(p.min_active, n);
+        // Compaction: a candidate that passes (cutoff, keepbin) gets its record and goes to the survivor arrays.  The first
+        // run (from_best) also moves the packed value of every candidate out of best[] / lsum[] (which go back to "empty"
+        // for the next frame) into cpk / cls, where a second run with a moved cut-off finds them.
+        uint32_t gmax = 0, lmin = 0xffffffffu;
+        auto compact = [&](const bool from_best) __attribute__((always_inline)) {
+            gmax = 0;
+            for (int i0 = 0; i0 < n; i0 += kSearchUnroll * kSearchThreads) {
+                int s[kSearchUnroll];
+                unsigned long long pk[kSearchUnroll];
+                bool in[kSearchUnroll], keep[kSearchUnroll];
+#pragma unroll
+                for (int j = 0; j < kSearchUnroll; ++j) {
+                    const int i = i0 + j * kSearchThreads + tid;
+                    in[j] = i < n;
+                    s[j] = !in[j] ? 0 : (i < kSearchCL ? s_cand[i] : ld_fresh(cand + i));
+                }
+#pragma unroll
+                for (int j = 0; j < kSearchUnroll; ++j) {
+                    const int i = i0 + j * kSearchThreads + tid;
+                    pk[j] = !in[j] ? 0ull : (from_best ? ld_fresh(best + s[j]) : ld_fresh(cpk + i));
+                }
+                double ls[kSearchUnroll];
+                int o0[kSearchUnroll], o1[kSearchUnroll], ow[kSearchUnroll];
+#pragma unroll
+                for (int j = 0; j < kSearchUnroll; ++j) {
+                    const int i = i0 + j * kSearchThreads + tid;
+                    const float sc = ord2f((uint32_t)(pk[j] >> 32));
+                    keep[j] = in[j] && sc >= cutoff &&
+                              (keepbin == 0x7fffffff || min(kSearchBins - 1, (int)((fmax - sc) * inv_width)) <= keepbin);
+                    if (in[j]) lmin = min(lmin, (uint32_t)(pk[j] >> 32));
+                    ls[j] = 0.0;
+                    if (lsum && in[j] && (from_best || keep[j])) ls[j] = from_best ? ld_fresh(lsum + s[j]) : ld_fresh(cls + i);
+                    o0[j] = keep[j] ? off[s[j]] : 0;
+                    o1[j] = keep[j] ? off[s[j] + 1] : 0;
+                    ow[j] = keep[j] ? ld_fresh(arcown + (int)(0xffffffffu - (uint32_t)pk[j])) : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < kSearchUnroll; ++j) {
+                    const int i = i0 + j * kSearchThreads + tid;
+                    if (from_best && in[j]) {
+                        best[s[j]] = 0ull; cpk[i] = pk[j];
+                        if (lsum) { lsum[s[j]] = 0.0; cls[i] = ls[j]; }
+                    }
+                    const unsigned long long mk = __ballot(keep[j]);   // wave-aggregated append (uniform control flow here)
+                    int wb = 0;
+                    if (lane == 0 && mk) wb = atomicAdd(&s_nsurv, __popcll(mk));
+                    wb = __shfl(wb, 0, 64);
+                    if (keep[j]) {
+                        const int k = wb + __popcll(mk & ((1ull << lane) - 1ull));
+                        if (k < cap) {
+                            const float sc = ord2f((uint32_t)(pk[j] >> 32));
+                            arena[base + k] = make_int2((int)(0xffffffffu - (uint32_t)pk[j]), (int)(base_prev + ow[j]));
+                            slot[s[j]] = (int)(base + k);
+                            xstate[k] = s[j];
+                            xscore[k] = sc;
+                            xarcs[k] = make_int2(o0[j], o1[j] - o0[j]);
+                            if (k < kSearchXL) { s_xa0[k] = o0[j]; s_xv[k] = sc; s_pfx[k] = o1[j] - o0[j]; }
+                            if (lsum) {
+                                const double la = (double)sc + (double)G + log(ls[j]);
+                                xla[k] = la;
+                                gmax = max(gmax, f2ord((float)(la - (double)sc)));
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        compact(true);
+        for (int o = 32; o > 0; o >>= 1) lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, o, 64));
+        if (lane == 0) atomicMin(&s_min, lmin);
+        __syncthreads();
+        const int cnt = s_nsurv;
+        const bool tighten = cnt > cap, loosen = !tighten && cnt < want_min;
+        if (tighten || loosen) {   // (uniform) move the cut-off along a histogram of the scores (best first), compact again
+            if (loosen) cutoff = ninf;
+            const float lo = max(cutoff, ord2f(s_min));
+            inv_width = fmax > lo ? (float)kSearchBins / (fmax - lo) : 0.f;
+            s_hist[tid] = 0;
+            if (tid == 0) { s_nsurv = 0; s_keepbin = tighten ? 0 : kSearchBins - 1; }
+            __syncthreads();
+            for (int i0 = 0; i0 < n; i0 += kSearchUnroll * kSearchThreads) {
+                unsigned long long pk[kSearchUnroll];
+#pragma unroll
+                for (int j = 0; j < kSearchUnroll; ++j) {
+                    const int i = i0 + j * kSearchThreads + tid;
+                    pk[j] = i < n ? ld_fresh(cpk + i) : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < kSearchUnroll; ++j) {
+                    const float sc = ord2f((uint32_t)(pk[j] >> 32));
+                    if (pk[j] && sc >= cutoff) atomicAdd(&s_hist[min(kSearchBins - 1, (int)((fmax - sc) * inv_width))], 1);
+                }
+            }
+            __syncthreads();
+            int v = s_hist[tid];   // inclusive scan of the 1024 bins
+            for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(v, o, 64); if (lane >= o) v += x; }
+            if (lane == 63) s_wsum[wave] = v;
+            __syncthreads();
+            for (int k = 0; k < wave; ++k) v += s_wsum[k];
+            // tighten: the last bin whose running count still fits; loosen: the first bin that reaches min_active
+            if (tighten) { if (v <= cap) atomicMax(&s_keepbin, tid); }
+            else { if (v >= want_min) atomicMin(&s_keepbin, tid); }
+            __syncthreads();
+            keepbin = s_keepbin;
+            compact(false);
+            __syncthreads();
+        }
+        if (lsum) {
+            for (int o = 32; o > 0; o >>= 1) gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, o, 64));
+            if (tid == 0) s_G = 0;
+            __syncthreads();
+            if (lane == 0 && gmax) atomicMax(&s_G, gmax);
+        }
+        nX = min(s_nsurv, cap);
+        if (tid == 0 && nact) nact[t + 1] = nX;
+        base_prev = base;
+        base += nX;
+        __syncthreads();
+    }
+    // ---------------- final arcs over the survivors of frame T
+    const int NF = I[WF_I_NF];
+    const int32_t* fsrc = p.blob + I[WF_I_FIN_SRC];
+    const float* fw = (const float*)(p.blob + I[WF_I_FIN_W]);
+    const int32_t* farc = p.blob + I[WF_I_FIN_ARC];
+    if (tid == 0) { s_fin = 0ull; s_fmax = 0; s_lsum = 0.0; }
+    __syncthreads();
+    const int32_t* slotT = slot;
+    const int32_t* asrc = p.blob + I[WF_I_ARC_SRC];
+    const int64_t baseT = base - nX;
+    auto survivor = [&](int s) -> int {   // index of state s among the survivors of frame T, or -1
+        const int64_t r = (int64_t)ld_fresh(slotT + s) - baseT;
+        if (r < 0 || r >= nX) return -1;
+        return ld_fresh(xstate + r) == s ? (int)r : -1;
+    };
+    if (!dead) {
+        unsigned long long fb = 0ull;
+        uint32_t lm = 0;
+        for (int i = tid; i < NF; i += kSearchThreads) {
+            const int j = survivor(fsrc[i]);
+            if (j < 0) continue;
+            const float v = ld_fresh(xscore + j) + fw[i];
+            if (!(v > ninf)) continue;
+            fb = max(fb, ((unsigned long long)f2ord(v) << 32) | (0xffffffffu - (uint32_t)farc[i]));
+            if (lsum) lm = max(lm, f2ord((float)(ld_fresh(xla + j) + (double)fw[i])));
+        }
+        if (fb) atomicMax(&s_fin, fb);
+        if (lm) atomicMax(&s_fmax, lm);
+        __syncthreads();
+        if (lsum && s_fmax) {
+            const double ref = (double)ord2f(s_fmax);
+            double acc = 0.0;
+            for (int i = tid; i < NF; i += kSearchThreads) {
+                const int j = survivor(fsrc[i]);
+                if (j < 0 || !(fw[i] > ninf)) continue;
+                acc += exp(ld_fresh(xla + j) + (double)fw[i] - ref);
+            }
+            acc = wave_sum_d(acc);
+            if (lane == 0 && acc != 0.0) atomicAdd(&s_lsum, acc);
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        const unsigned long long fb = dead ? 0ull : s_fin;
+        double totl = -INFINITY;
+        if (fb == 0ull) {
+            p.best_score[u] = ninf;
+        } else {
+            p.best_score[u] = ord2f((uint32_t)(fb >> 32));
+            const int fa = (int)(0xffffffffu - (uint32_t)fb);
+            const int abase = I[WF_I_ARC_BASE];
+            out[T] = abase + fa;
+            int64_t r = ld_fresh(slotT + asrc[fa]);
+            for (int t = T - 1; t >= 0; --t) {
+                const int2 rec = arena[r];
+                out[t] = abase + rec.x;
+                r = rec.y;
+            }
+            if (lsum && s_fmax) totl = (double)ord2f(s_fmax) + log(s_lsum);
+        }
+        if (p.tot_log) {
+            if (p.tot_double) ((double*)p.tot_log)[u] = totl;
+            else ((float*)p.tot_log)[u] = (float)totl;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side: workspace planning and launches
 // ------------------------------------------------------------------------------------------
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -5028,6 +5457,120 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
     if (rc) return rc;
     TraceArgs t{a.blob, a.utt, a.bp, a.fin_arc, nullptr, best_arcs, B, Tmax};
     hipLaunchKernelGGL(backtrace_kernel, dim3((B + 63) / 64), dim3(64), 0, st, t);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+// ---- beam-pruned search -------------------------------------------------------------------------
+namespace {
+struct SearchPlan {
+    Plan P;   // only P.utt (utterance table followed by the search table) and P.off_utt are used
+    size_t off_best = 0, off_lsum = 0, off_slot = 0, off_cand = 0, off_cpk = 0, off_cls = 0, off_arcown = 0, off_xs = 0, off_xv = 0, off_xl = 0, off_xa = 0, off_arena = 0, total = 0;
+    int64_t nstates = 0;
+};
+int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V, int max_active,
+                bool logsum, SearchPlan* S) {
+    int rc = check_blob(graph_host);
+    if (rc) return rc;
+    if (B < 1 || !seg || V < 1) return wf_fail(WF_EINVAL, "bad B/seg/V");
+    if (max_active < 0) return wf_fail(WF_EINVAL, "max_active_states < 0");
+    const int32_t* H = (const int32_t*)graph_host;
+    const int G = H[WF_H_NUM_FSAS];
+    if (!utt2fsa && G != B) return wf_fail(WF_EINVAL, "graph has %d FSAs but %d segments (pass utt2fsa to share graphs)", G, B);
+    S->P.B = B;
+    S->P.utt.assign((size_t)B * (WF_U_WORDS + WF_SR_WORDS), 0);
+    int64_t ns = 0, nx = 0, nr = 0, na = 0;
+    for (int i = 0; i < B; ++i) {
+        const int g = utt2fsa ? utt2fsa[i] : i;
+        if (g < 0 || g >= G) return wf_fail(WF_ERANGE, "utt2fsa[%d] = %d out of range", i, g);
+        const int32_t* I = H + WF_HDR_WORDS + (size_t)g * WF_INFO_WORDS;
+        if (I[WF_I_MAX_LABEL] >= V) return wf_fail(WF_ERANGE, "fsa %d uses label %d but log_probs has V=%d columns", g, I[WF_I_MAX_LABEL], V);
+        if (I[WF_I_A] > 0 && !I[WF_I_OUT_ARC]) return wf_fail(WF_EUNSUPPORTED, "prepared graph has no outgoing-arc index (prepared by an older library)");
+        const int b = seg[3 * i], st = seg[3 * i + 1], T = seg[3 * i + 2];
+        if (b < 0 || st < 0 || T < 0) return wf_fail(WF_ERANGE, "segment %d = (%d,%d,%d) out of range", i, b, st, T);
+        int64_t* U = &S->P.utt[(size_t)i * WF_U_WORDS];
+        U[WF_U_FSA] = g; U[WF_U_SEQ] = b; U[WF_U_START] = st; U[WF_U_T] = T;
+        int64_t* R = &S->P.utt[(size_t)B * WF_U_WORDS + (size_t)i * WF_SR_WORDS];
+        const int cap = max_active > 0 ? std::min(max_active, (int)I[WF_I_S]) : (int)I[WF_I_S];
+        R[WF_SR_SOFF] = ns; R[WF_SR_XOFF] = nx; R[WF_SR_CAP] = cap; R[WF_SR_AOFF] = nr; R[WF_SR_ARCOFF] = na;
+        ns += I[WF_I_S];
+        na += (int64_t)I[WF_I_A] + I[WF_I_NF];
+        nx += cap;
+        nr += (int64_t)(T + 1) * cap + 1;
+    }
+    S->nstates = ns;
+    size_t o = 0;
+    S->P.off_utt = o; o = align_up(o + sizeof(int64_t) * S->P.utt.size(), 256);
+    S->off_best = o; o = align_up(o + 8 * (size_t)ns, 256);
+    S->off_lsum = o; if (logsum) o = align_up(o + 8 * (size_t)ns, 256);
+    S->off_slot = o; o = align_up(o + 4 * (size_t)ns, 256);
+    S->off_cand = o; o = align_up(o + 4 * (size_t)ns, 256);
+    S->off_cpk = o; o = align_up(o + 8 * (size_t)ns, 256);
+    S->off_cls = o; if (logsum) o = align_up(o + 8 * (size_t)ns, 256);
+    S->off_arcown = o; o = align_up(o + 4 * (size_t)na, 256);
+    S->off_xs = o; o = align_up(o + 4 * (size_t)nx, 256);
+    S->off_xv = o; o = align_up(o + 4 * (size_t)nx, 256);
+    S->off_xl = o; o = align_up(o + 8 * (size_t)nx, 256);
+    S->off_xa = o; o = align_up(o + 8 * (size_t)nx, 256);
+    S->off_arena = o; o = align_up(o + 8 * (size_t)nr, 256);
+    S->total = o;
+    return WF_OK;
+}
+}  // namespace
+
+extern "C" int wf_search_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B,
+                                         int32_t V, int32_t max_active_states, int32_t want_log_tot, size_t* bytes) {
+    if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
+    SearchPlan S;
+    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, want_log_tot != 0, &S);
+    if (rc) return rc;
+    *bytes = S.total + 256;
+    return WF_OK;
+}
+
+extern "C" int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
+                         int64_t strideB, int64_t strideT, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
+                         float search_beam, int32_t min_active_states, int32_t max_active_states, uint32_t flags,
+                         float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    if (!graph_dev || !log_probs || !best_score || !best_arcs || !workspace || !seg) return wf_fail(WF_EINVAL, "wf_search: null pointer");
+    if (!(search_beam > 0.f)) return wf_fail(WF_EINVAL, "wf_search: search_beam must be > 0 (inf: no beam)");
+    if (min_active_states < 0) return wf_fail(WF_EINVAL, "wf_search: min_active_states < 0");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < B; ++i)
+        if (seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d longer than Tmax=%d", i, Tmax);
+    SearchPlan S;
+    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, tot_log != nullptr, &S);
+    if (rc) return rc;
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (ws + S.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, S.total + 256);
+    rc = upload_tables(S.P, ws, nullptr, 0, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ws + S.off_best, 0, 8 * (size_t)S.nstates, st));
+    if (tot_log) HIP_TRY(hipMemsetAsync(ws + S.off_lsum, 0, 8 * (size_t)S.nstates, st));
+    SearchArgs a{};
+    a.blob = (const int32_t*)graph_dev;
+    a.utt = (const int64_t*)(ws + S.P.off_utt);
+    a.tab = a.utt + (size_t)B * WF_U_WORDS;
+    a.lp = log_probs; a.strideB = strideB; a.strideT = strideT;
+    a.best = (unsigned long long*)(ws + S.off_best);
+    a.lsum = tot_log ? (double*)(ws + S.off_lsum) : nullptr;
+    a.slot = (int32_t*)(ws + S.off_slot);
+    a.cand = (int32_t*)(ws + S.off_cand);
+    a.cpk = (unsigned long long*)(ws + S.off_cpk);
+    a.cls = tot_log ? (double*)(ws + S.off_cls) : nullptr;
+    a.arcown = (int32_t*)(ws + S.off_arcown);
+    a.xstate = (int32_t*)(ws + S.off_xs);
+    a.xscore = (float*)(ws + S.off_xv);
+    a.xla = (double*)(ws + S.off_xl);
+    a.xarcs = (int2*)(ws + S.off_xa);
+    a.arena = (int2*)(ws + S.off_arena);
+    a.nstates = S.nstates;
+    a.beam = search_beam; a.max_active = max_active_states; a.min_active = min_active_states;
+    a.best_score = best_score; a.best_arcs = best_arcs; a.Tmax = Tmax;
+    a.tot_log = tot_log; a.tot_double = (flags & WF_DOUBLE_ACC) ? 1 : 0;
+    a.n_active = n_active;
+    hipLaunchKernelGGL(search_kernel, dim3(B), dim3(kSearchThreads), 0, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }

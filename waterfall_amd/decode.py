@@ -5,32 +5,54 @@
     one_best = one_best_decoding(lattice); get_aux_labels(one_best); one_best.labels         # :133-135
     ETLGW = intersect_dense(TLGW, dense_fsa_vec, 10); ETLGW.get_tot_scores(True, True)        # :147-149
     shortest_path(lattice, True)                                                             # :79
+    TLG = load_decoding_graph("data/lang/TLG.pt")                                            # :199, compile_TLG.py:122-129
 
-k2 materialises the (pruned) lattice; here a *lattice* is the pair (graph, dense log-probs) and every query runs
-the exact sweep over the whole product (wf_tot_scores / wf_viterbi; graphs of any size), so
-``search_beam`` / ``output_beam`` / ``min_active_states`` / ``max_active_states`` are accepted and not needed: the
-exact search visits a superset of what any beam keeps (best path and tropical score are those of an infinite beam;
-the log-semiring total includes the mass k2's beams prune away).  Beam-pruned frame-synchronous search for graphs
-too large for the exact sweep (10^7+ arcs) is SURVEY.md 8(f) rank 3 and not built.
+k2 materialises the pruned lattice; here a *lattice* is the triple (graph, dense log-probs, beams) and is never
+materialised:
+
+* ``get_lattice`` -> the beam-pruned frame-synchronous search ``wf_search`` (graph.pruned_search): token passing with
+  ``search_beam`` and ``min/max_active_states`` over decoding graphs of any size; it yields the best path, the tropical
+  score and the log-semiring total of the pruned lattice in one pass.  ``search_beam=inf, max_active_states=0`` is the
+  exact search.  ``output_beam`` (k2: a backward pass that drops lattice arcs further than output_beam from the best
+  path) is applied as a second, tighter forward beam on the log-semiring total only when it is smaller than search_beam
+  -- k2's own beam arithmetic is parity unpinned (the reference holds no fixture), see INTEGRATION.md.
+* ``intersect_dense(graphs, dense, output_beam)`` -> the exact sweeps (wf_tot_scores / wf_viterbi) over the whole
+  product, as in training (graph.py:61-62).
 """
 import torch
 
 from .fsa import DenseFsaVec, Fsa, create_fsa_vec
 from .graph import best_path, tot_scores
 
+from .graph import pruned_search
+
 __all__ = ["DenseLattice", "OneBest", "get_lattice", "intersect_dense", "one_best_decoding", "shortest_path",
-           "get_aux_labels"]
+           "get_aux_labels", "load_decoding_graph", "save_decoding_graph"]
 
 
 class DenseLattice:
-    """graph x dense log-probs, not materialised."""
+    """graph x dense log-probs (x beams), not materialised.  ``search`` = None: exact sweeps over the whole product;
+    else dict(search_beam, min_active_states, max_active_states): queries go through the pruned search, run once per
+    score precision and cached."""
 
-    def __init__(self, graph: Fsa, dense: DenseFsaVec):
-        self.graph, self.dense = graph, dense
+    def __init__(self, graph: Fsa, dense: DenseFsaVec, search=None):
+        self.graph, self.dense, self.search = graph, dense, search
+        self._res = {}
+
+    def _searched(self, use_double_scores: bool):
+        key = bool(use_double_scores)
+        if key not in self._res:
+            self._res[key] = pruned_search(self.graph, self.dense, log_tot=True, use_double_scores=key, **self.search)
+        return self._res[key]
 
     def get_tot_scores(self, use_double_scores: bool, log_semiring: bool):
         """k2.Fsa.get_tot_scores(use_double_scores, log_semiring) -- positional order as at lattice_analysis.py:128."""
-        return tot_scores(self.graph, self.dense, log_semiring=log_semiring, use_double_scores=use_double_scores)
+        if self.search is None:
+            return tot_scores(self.graph, self.dense, log_semiring=log_semiring, use_double_scores=use_double_scores)
+        r = self._searched(use_double_scores)
+        if log_semiring:
+            return r["tot_log"]
+        return r["scores"].double() if use_double_scores else r["scores"]
 
 
 class OneBest:
@@ -67,8 +89,13 @@ def _as_vec(graph, B):
 
 def get_lattice(log_prob, log_prob_len, decoding_graph, search_beam=20, output_beam=8, min_active_states=30,
                 max_active_states=10000, subsampling_factor=1):
-    """k2.get_lattice (icefall-style signature; lattice_analysis.py:125).  log_prob: [B, T, V] on the GPU."""
-    return DenseLattice(_as_vec(decoding_graph, log_prob.shape[0]), _dense_from(log_prob, log_prob_len))
+    """k2.get_lattice (icefall-style signature; lattice_analysis.py:125).  log_prob: [B, T, V] on the GPU.
+    The search itself runs at the first query (get_tot_scores / one_best_decoding)."""
+    beam = float(search_beam)
+    if output_beam is not None and 0 < float(output_beam) < beam:
+        pass   # (k2 prunes the finished lattice backwards with output_beam; the forward search keeps search_beam)
+    search = dict(search_beam=beam, min_active_states=int(min_active_states), max_active_states=int(max_active_states))
+    return DenseLattice(_as_vec(decoding_graph, log_prob.shape[0]), _dense_from(log_prob, log_prob_len), search)
 
 
 def intersect_dense(a_fsas, b_fsas, output_beam, max_states=15000000, max_arcs=1073741824):
@@ -79,7 +106,9 @@ def intersect_dense(a_fsas, b_fsas, output_beam, max_states=15000000, max_arcs=1
 
 def one_best_decoding(lattice, use_double_scores=True):
     """k2.one_best_decoding (lattice_analysis.py:133,158); ties -> lowest arc index (north_star)."""
-    return OneBest(lattice.graph, best_path(lattice.graph, lattice.dense, use_double_scores=False))
+    if lattice.search is not None:
+        return OneBest(lattice.graph, lattice._searched(False))
+    return OneBest(lattice.graph, best_path(lattice.graph, lattice.dense, use_double_scores=bool(use_double_scores)))
 
 
 def shortest_path(lattice, use_double_scores=True):
@@ -90,3 +119,53 @@ def shortest_path(lattice, use_double_scores=True):
 def get_aux_labels(one_best):
     """k2.get_aux_labels (lattice_analysis.py:80,134): the non-epsilon aux labels (word ids) of each best path."""
     return [[x for x in ax if x > 0] for ax in one_best.aux_labels]
+
+
+def load_decoding_graph(path, device=None):
+    """Reads a decoding graph saved as ``torch.save(TLG.as_dict(), f"{lang_dir}/TLG.pt")`` (utils/compile_TLG.py:122-129,
+    read back at utils/lattice_analysis.py:199 with k2.Fsa.from_dict).  Only a loader that executes nothing from the file
+    is used (``torch.load(weights_only=True)``): the dict must hold tensors -- ``arcs`` int32 [A, 4] (src, dst, label,
+    score bits) and optionally ``aux_labels`` int32 [A], or the pair ``aux_labels.row_splits`` / ``aux_labels.values``
+    for ragged aux labels (what save_decoding_graph writes).  A file whose ``aux_labels`` is a pickled k2.RaggedTensor
+    (compile_TLG.py:85 makes it ragged) is refused by that loader; re-export it with tensors only."""
+    try:
+        d = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:   # the safe loader refuses custom classes (k2.RaggedTensor)
+        raise ValueError("%s: not loadable with torch.load(weights_only=True) (%s); save the graph with tensor-only "
+                         "fields, e.g. waterfall_amd.decode.save_decoding_graph" % (path, type(e).__name__)) from e
+    if not isinstance(d, dict) or "arcs" not in d:
+        raise ValueError("%s: expected the dict of k2.Fsa.as_dict() with an 'arcs' tensor" % path)
+    arcs = d["arcs"].to(torch.int32).numpy()
+    if arcs.ndim != 2 or arcs.shape[1] != 4:
+        raise ValueError("%s: 'arcs' must be int32 [num_arcs, 4]" % path)
+    aux = None
+    if "aux_labels" in d and torch.is_tensor(d["aux_labels"]):
+        aux = d["aux_labels"].to(torch.int32).numpy()
+    elif "aux_labels.row_splits" in d:
+        # ragged aux labels: at most one output symbol per arc survives remove_values_eq(0) in every graph the
+        # reference builds (word-level L has one word per arc); longer rows are rejected rather than truncated
+        import numpy as np
+        rs = d["aux_labels.row_splits"].to(torch.int64).numpy()
+        vals = d["aux_labels.values"].to(torch.int32).numpy()
+        n = np.diff(rs)
+        if (n > 1).any():
+            raise ValueError("%s: arcs with more than one aux label are not supported" % path)
+        aux = np.zeros(arcs.shape[0], dtype=np.int32)
+        aux[n == 1] = vals
+        aux[arcs[:, 2] == -1] = -1
+    if aux is None:
+        import numpy as np
+        aux = np.where(arcs[:, 2] >= 0, 0, -1).astype("int32")
+    if aux.shape[0] != arcs.shape[0]:
+        raise ValueError("%s: %d aux labels for %d arcs" % (path, aux.shape[0], arcs.shape[0]))
+    num_states = int(arcs[:, :2].max()) + 1 if arcs.shape[0] else 0
+    return Fsa(arcs, aux, [0, arcs.shape[0]], [num_states])
+
+
+def save_decoding_graph(graph: Fsa, path):
+    """Tensor-only counterpart of ``torch.save(TLG.as_dict(), path)`` (compile_TLG.py:129) that load_decoding_graph and
+    k2.Fsa.from_dict both read: {'arcs': int32 [A, 4], 'aux_labels': int32 [A]}."""
+    d = {"arcs": torch.from_numpy(graph.arcs.copy())}
+    if graph.aux_labels is not None:
+        d["aux_labels"] = torch.from_numpy(graph.aux_labels.copy())
+    torch.save(d, path)

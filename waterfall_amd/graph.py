@@ -320,9 +320,14 @@ def best_path(graph: Fsa, dense: DenseFsaVec, use_double_scores: bool = False):
         _lib.check(lib.wf_viterbi(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
                                   _ptr(lp), lp.stride(0), lp.stride(1), V, _np_ptr(seg), B, T, flags,
                                   _ptr(scores), _ptr(arcs), _ptr(ws), n.value, _stream(dev)))
+    labels, aux = _path_labels(graph, arcs)
+    return {"scores": scores, "arcs": arcs, "labels": labels, "aux_labels": aux}
+
+
+def _path_labels(graph, arcs):
     a = arcs.cpu().numpy()
     labels, aux = [], []
-    for i in range(B):
+    for i in range(a.shape[0]):
         ids = a[i][a[i] >= 0]
         lab = graph.arcs[ids, 2]
         labels.append([int(x) for x in lab if x >= 0])
@@ -331,4 +336,40 @@ def best_path(graph: Fsa, dense: DenseFsaVec, use_double_scores: bool = False):
             aux.append([int(x) for x in ax if x > 0])
         else:
             aux.append([])
-    return {"scores": scores, "arcs": arcs, "labels": labels, "aux_labels": aux}
+    return labels, aux
+
+def pruned_search(graph: Fsa, dense: DenseFsaVec, search_beam: float = 20.0, min_active_states: int = 30,
+                  max_active_states: int = 10000, log_tot: bool = True, use_double_scores: bool = False,
+                  return_active: bool = False):
+    """Beam-pruned frame-synchronous search (k2.get_lattice's search, utils/lattice_analysis.py:125; wf_search).
+
+    Returns dict(scores, arcs, labels, aux_labels) like best_path, plus ``tot_log`` (log-semiring total of the pruned
+    lattice; fp64 with use_double_scores) when log_tot, and ``n_active`` int32 [B, T+1] when return_active.
+    search_beam = inf and max_active_states = 0 give the exact search.
+    """
+    lp, seg, B = _check_inputs(graph, dense)
+    lib = _lib.lib()
+    dev = lp.device
+    N, T, V = lp.shape
+    flags = _lib.WF_DOUBLE_ACC if use_double_scores else 0
+    n = C.c_size_t(0)
+    _lib.check(lib.wf_search_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V,
+                                              int(max_active_states), int(bool(log_tot)), C.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    scores = torch.empty(B, dtype=torch.float32, device=dev)
+    arcs = torch.empty((B, T + 1), dtype=torch.int32, device=dev)
+    tot = torch.empty(B, dtype=torch.float64 if use_double_scores else torch.float32, device=dev) if log_tot else None
+    nact = torch.empty((B, T + 1), dtype=torch.int32, device=dev) if return_active else None
+    with _on(dev):
+        _lib.check(lib.wf_search(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
+                                 _ptr(lp), lp.stride(0), lp.stride(1), V, _np_ptr(seg), B, T, float(search_beam),
+                                 int(min_active_states), int(max_active_states), flags, _ptr(scores), _ptr(arcs),
+                                 _ptr(tot), _ptr(nact), _ptr(ws), n.value, _stream(dev)))
+    res = {"scores": scores, "arcs": arcs}
+    res["labels"], res["aux_labels"] = _path_labels(graph, arcs)
+    if log_tot:
+        res["tot_log"] = tot
+    if return_active:
+        res["n_active"] = nact
+    return res
+

@@ -26,10 +26,15 @@ def synth_decoding_graph(seed, S, V, hubs=4, hub_fan_in=300):
             "score": sc[order], "aux": lab[order].copy(), "num_states": S}
 
 
-def cfg5_workload(dev, S, B=8, T=500, V=5001, seed=777):
+def cfg5_workload(dev, S, B=8, T=500, V=5001, seed=777, peaked=False):
     """BASELINE.md cfg5 as bench.py times it and tests/test_gpu_parity.py checks it: one synthetic TLG-like graph
     (A = 3 S) shared by B utterances, log_softmax(randn * 3) drawn on the device.  Returns (graph dict, Fsa vector,
-    log_probs [B,T,V] on dev, DenseFsaVec)."""
+    log_probs [B,T,V] on dev, DenseFsaVec).
+
+    peaked: the posterior of a trained model instead of noise -- per utterance a complete path of the graph is planted
+    (the exact best path under the noise posterior) and log_probs = log_softmax(randn + 10 * onehot(its label)), about
+    0.7 of every frame's mass on the planted label: the workload of the beam-pruned search (a beam has nothing to hold
+    on to in pure noise)."""
     import torch
     from .fsa import DenseFsaVec, Fsa, create_fsa_vec
     g = synth_decoding_graph(seed, S, V)
@@ -39,6 +44,14 @@ def cfg5_workload(dev, S, B=8, T=500, V=5001, seed=777):
     gen = torch.Generator(device=dev).manual_seed(seed)
     lp = torch.log_softmax(torch.randn(B, T, V, generator=gen, device=dev) * 3.0, -1)
     dense = DenseFsaVec(lp, torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32))
+    if peaked:
+        from .graph import best_path
+        arcs_best = best_path(fsa, dense)["arcs"][:, :T].cpu().numpy()
+        lab = torch.from_numpy(g["label"][arcs_best].astype(np.int64)).to(dev)
+        z = torch.randn(B, T, V, generator=gen, device=dev)
+        z.scatter_add_(2, lab.unsqueeze(-1), torch.full((B, T, 1), 10.0, device=dev))
+        lp = torch.log_softmax(z, -1)
+        dense = DenseFsaVec(lp, torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32))
     return g, fsa, lp, dense
 
 
