@@ -2310,6 +2310,13 @@ struct BigArgs {
     int shared_S;       // != 0: alpha is in the shared-graph layout [parity][group][state][kNB] (big_step_shared_kernel)
     int shared_par;     //       and every utterance's alpha_T is in buffer shared_par
     int shared_groups;
+    // output_beam pruning (MASK): tropical alpha / beta rows of a first pass, its best scores, the beam; lattice arc
+    // (t, a) is kept iff mA_t[src] + (w + e) + mB_{t+1}[dst] >= best - beam (the rule of sweep_kernel's masked pass)
+    const float* mA;
+    const float* mB;
+    const float* best;
+    float* thr;
+    float beam;
 };
 
 template <typename Acc, bool TROP>
@@ -2328,7 +2335,7 @@ __global__ void __launch_bounds__(256) big_init_kernel(BigArgs p) {
 }
 
 // DIR 0: alpha_{t+1} from alpha_t over the incoming arcs; DIR 1: beta_t from beta_{t+1} over the outgoing arcs
-template <typename Acc, typename Sum, bool TROP, int DIR>
+template <typename Acc, typename Sum, bool TROP, int DIR, bool MASK = false>
 __global__ void __launch_bounds__(256) big_step_kernel(BigArgs p) {
     __shared__ double redv[8];   // (m, s) pairs of 4 waves; Acc <= double
     __shared__ int reda[4];
@@ -2358,6 +2365,11 @@ __global__ void __launch_bounds__(256) big_step_kernel(BigArgs p) {
     const float* erow = I[WF_I_DIRECT] ? p.lp + U[WF_U_SEQ] * p.strideB + (U[WF_U_START] + p.t) * p.strideT
                                         : p.E + U[WF_U_E] + (int64_t)p.t * K;
     int32_t* bprow = (!DIR && p.bp) ? p.bp + U[WF_U_ALPHA] + (int64_t)p.t * S : nullptr;
+    const float* mra = MASK ? p.mA + U[WF_U_ALPHA] + (int64_t)p.t * S : nullptr;
+    const float* mrb = MASK ? p.mB + U[WF_U_BETA] + (int64_t)(p.t + 1) * S : nullptr;
+    const float mthr = MASK ? p.best[u] - p.beam : 0.f;
+    // (s: the state this lane / workgroup reduces into; o: the arc's other end -- its source going forward)
+    auto kept = [&](int s, int o, float we) { return !MASK || mra[DIR ? s : o] + we + mrb[DIR ? o : s] >= mthr; };
     if ((int)blockIdx.x < p.nlb) {
         const int s = blockIdx.x * 256 + tid;
         if (s >= S) return;
@@ -2367,6 +2379,7 @@ __global__ void __launch_bounds__(256) big_step_kernel(BigArgs p) {
         Sum sm = 0;
         int barc = 0x7fffffff;
         for (int a = a0; a < a1; ++a) {
+            if (MASK && !kept(s, oth[a], w[a] + erow[col[a]])) continue;
             const Acc v = cur[oth[a]] + (Acc)(w[a] + erow[col[a]]);
             if (TROP) max_push(m, barc, v, DIR ? 0 : aid[a]);
             else lse_push(m, sm, v);
@@ -2382,6 +2395,7 @@ __global__ void __launch_bounds__(256) big_step_kernel(BigArgs p) {
         Sum sm = 0;
         int barc = 0x7fffffff;
         for (int a = a0 + tid; a < a1; a += 256) {
+            if (MASK && !kept(s, oth[a], w[a] + erow[col[a]])) continue;
             const Acc v = cur[oth[a]] + (Acc)(w[a] + erow[col[a]]);
             if (TROP) max_push(m, barc, v, DIR ? 0 : aid[a]);
             else lse_push(m, sm, v);
@@ -2638,6 +2652,7 @@ __global__ void __launch_bounds__(256) big_final_kernel(BigArgs p) {
         else ((float*)p.tot)[u] = (float)val;
         if (p.totd) p.totd[u] = (double)val;
         if (p.fin_arc) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
+        if (p.thr) p.thr[u] = p.best[u] - p.beam;
     }
 }
 
@@ -3070,7 +3085,12 @@ __global__ void __launch_bounds__(256) post_big_kernel(PostArgs p) {
     // row format: scaled probabilities + shifts (linear-domain sweep) or natural-log scores (log-semiring sweep / fallback)
     const bool lin = p.lin && !p.flag[u];
     const double cst = lin ? lin_post_const(p, U, u, t, T) : 0.0;
+    const bool masked = p.mA != nullptr;   // output_beam pruning: the kept lattice arcs only (rule of the masked sweeps)
+    const float* mra = masked ? p.mA + U[WF_U_ALPHA] + (int64_t)t * S : nullptr;
+    const float* mrb = masked ? p.mB + U[WF_U_BETA] + (int64_t)(t + 1) * S : nullptr;
+    const float mthr = masked ? p.thr[u] : 0.f;
     auto post = [&](int a, float e) {
+        if (masked && !(mra[lsrc[a]] + (lw[a] + e) + mrb[ldst[a]] >= mthr)) return 0.f;
         if (lin) {
             double ea, eb;
             float fa, fb;
@@ -4153,8 +4173,6 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     // graphs whose sweep state does not fit the LDS (or, test hook, with at least WF_BIG_MIN_S states): per-frame launches
     P->big = sweep_lds_bytes(*P, acc_bytes) > kLdsBudget || P->smax >= hk().big_min_s;
     if (mode == 0) {
-        if (P->big && pruned)
-            return wf_fail(WF_EUNSUPPORTED, "output_beam pruning is not available for graphs beyond the LDS-resident sweeps (%d states)", P->smax);
         P->pruned = pruned;
         const bool hub_ok = hub_config(*P);
         P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok || hub_ok || linbig_config(*P));
@@ -4378,7 +4396,7 @@ size_t sweep_lds_bytes(const Plan& P, size_t acc_bytes) { return sweep_config(P,
 
 // big-graph sweep: init, one step launch per frame (and, with a.beta set, per direction: the backward
 // launches go to the side stream and run beside the forward ones), final reduction
-template <typename Acc, typename Sum, bool TROP>
+template <typename Acc, typename Sum, bool TROP, bool MASK = false>
 int launch_big(const Plan& P, BigArgs a, int B, hipStream_t st) {
     a.nstates = P.nstates;
     a.nlb = (P.smax + 255) / 256;
@@ -4395,14 +4413,14 @@ int launch_big(const Plan& P, BigArgs a, int B, hipStream_t st) {
         BigArgs b = a;
         for (int t = P.Tlong - 1; t >= 0; --t) {
             b.t = t;
-            hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP, 1>), gridb, dim3(256), 0, side->stream2, b);
+            hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP, 1, MASK>), gridb, dim3(256), 0, side->stream2, b);
         }
         if ((rc = guard.record())) return rc;
     }
     const dim3 grid(a.nlb + P.nheavy_in_max, B);
     for (int t = 0; t < P.Tlong; ++t) {
         a.t = t;
-        hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP, 0>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((big_step_kernel<Acc, Sum, TROP, 0, MASK>), grid, dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL((big_final_kernel<Acc, Sum, TROP>), dim3(B), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
@@ -4898,7 +4916,6 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     // rows beyond the LDS, or long enough that staging them costs more than gathering per arc (measured on cfg4's
     // denominators, S = 10 002: 2.4 ms against 3.9 ms): gather from memory.  Log-domain, unpruned rows only.
     if (lds > kLdsBudget || ((!P.lin || P.linbig) && !P.pruned && P.smax >= hk().post_big_min_s)) {
-        if (P.pruned) return wf_fail(WF_EUNSUPPORTED, "internal: post_big_kernel needs unpruned rows");
         hipLaunchKernelGGL(post_big_kernel, dim3(Tmax, num_seqs), dim3(256), 0, st, q);
         HIP_TRY(hipGetLastError());
         return WF_OK;
@@ -5066,6 +5083,19 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
         if (rc) return rc;
         if ((rc = tm_record(7, st))) return rc;
         g_tm.check_from = 2;
+    } else if (pruned && P.big) {
+        // the same two passes with the per-frame launches of graphs beyond the LDS
+        BigArgs g{};
+        g.blob = a.blob; g.utt = a.utt; g.lp = log_probs; g.strideB = strideB; g.strideT = strideT; g.E = a.E;
+        g.alpha = ws + P.off_mA; g.beta = ws + P.off_mB; g.tot = ws + P.off_best; g.tot_double = 0;
+        rc = launch_big<float, float, true>(P, g, B, st);
+        if (rc) return rc;
+        g.alpha = a.alpha; g.beta = a.beta; g.tot = tot; g.totd = a.totd;
+        g.mA = (const float*)(ws + P.off_mA); g.mB = (const float*)(ws + P.off_mB);
+        g.best = (const float*)(ws + P.off_best); g.thr = (float*)(ws + P.off_thr); g.beam = output_beam;
+        rc = dbl ? launch_big<double, double, false, true>(P, g, B, st) : launch_big<double, float, false, true>(P, g, B, st);
+        if (rc) return rc;
+        if ((rc = tm_record(2, st))) return rc;
     } else if (pruned) {
         // pass 1: tropical forward-backward (fp32, every row kept); pass 2: log semiring over the kept arcs
         SweepCfg tc = sweep_config(P, 4);
