@@ -11,8 +11,12 @@ beside them on a side stream) -> row check -> posterior/gradient rows (loss + gr
 log_probs, reduction 'sum'), called through the C ABI (wf_fb_logsum).  The headline workload
 is BASELINE.json configs[2] (the configuration the metric is quoted on: B=32, T=500, V=5k, CTC
 numerator graphs, "cfg3" in BASELINE.md); with N GPUs every rank processes its own B=32 batch
-(weak scaling, utterances are independent) and the step ends with ONE RCCL all-reduce of the fused
-(loss_sum, n_frames, n_infeasible) buffer.
+(weak scaling, utterances are independent; --scaling strong deals ONE batch of 32 over the ranks, BASELINE.json's
+"B=32 sharded over 8 GPUs") and the step ends with ONE RCCL all-reduce of the fused (loss_sum, n_frames,
+n_infeasible [, V per-label gradient sums with --grad-sums]) buffer.  The timed region of exactly K steps is repeated
+until the regions add up to --min-region-ms (100); value / ms_per_step are the median region, *_min the fastest.
+(WF_BENCH_BACKEND=gloo runs the N > 1 path with several ranks on ONE GPU: a functional rehearsal only -- two processes
+time-slice the device with a quantum of ~0.1 s per switch, so its timings mean nothing.)
 
 Prints one JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, measured live with HIP
 events on the launch stream), "cpu_baseline" (oracle/dwfst_oracle.c, a scalar C port of the same
@@ -36,27 +40,48 @@ from waterfall_amd import _lib  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 KERNEL_NAMES = {"gather": "gather_lin_small_kernel", "sweep": "sweep_band_kernel", "post": "post_small_kernel",
-                "zero": "zero_flat_kernel", "check": "check_kernel"}
-PMC_FILE = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                "zero": "sweep_band_kernel (fill workgroups of the same launch)", "check": "rescue_kernel"}
+PROFILE_TAG = "r02"
+PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+STATS_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_bench_cfg3_kernel_stats.txt")
+META_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_meta.json")          # {"kernel_source_sha256": ...} at profiling time
+KERNEL_SOURCES = [os.path.join(ROOT, "waterfall_amd", "csrc", f) for f in ("wf_kernels.hip", "wf_internal.h")]
+
+
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def profiles_current():
+    """The committed rocprofv3 summaries describe THIS kernel source: their recorded source hash equals the tree's.  When
+    it does not (a kernel changed and the profiles were not regenerated) every field read from them is nulled."""
+    try:
+        return json.load(open(META_FILE))["kernel_source_sha256"] == kernel_source_hash()
+    except (OSError, KeyError, ValueError):
+        return False
 
 
 def pmc_traffic(kernel, is_default_workload):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read), or None when there is no
-    measurement for this workload."""
-    if not is_default_workload or not os.path.exists(PMC_FILE):
+    measurement for this workload and kernel source."""
+    if not is_default_workload or not os.path.exists(PMC_FILE) or not profiles_current():
         return None
-    k = json.load(open(PMC_FILE))["kernels"].get(KERNEL_NAMES.get(kernel, ""))
+    k = json.load(open(PMC_FILE))["kernels"].get(KERNEL_NAMES.get(kernel, "").split(" ")[0])
     return k["hbm_bytes_per_launch_fetch_doubled"] if k else None
 
+
 def rocprof_avg_us(kernel, is_default_workload):
-    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this command
-    (profiles/r01d_bench_cfg3_kernel_stats.txt), for comparison with the live HIP-event interval."""
-    path = os.path.join(ROOT, "profiles", "r01d_bench_cfg3_kernel_stats.txt")
-    name = KERNEL_NAMES.get(kernel, "")
-    if not is_default_workload or not name or not os.path.exists(path):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this command, for
+    comparison with the live HIP-event interval; None when the summary is of another kernel source."""
+    name = KERNEL_NAMES.get(kernel, "").split(" ")[0]
+    if not is_default_workload or not name or not os.path.exists(STATS_FILE) or not profiles_current():
         return None
-    for line in open(path):
+    for line in open(STATS_FILE):   # tools/prof_summary.py columns: calls total_us avg_us pct kernel
         if name in line:
             return float(line.split()[2])
     return None
@@ -88,26 +113,39 @@ def _np(a):
 class Workload:
     """Synthetic batch (seed 777 + rank) resident on one GPU."""
 
-    def __init__(self, name, B, T, dev, seed, ragged=False):
+    def __init__(self, name, B, T, dev, seed, ragged=False, shard=None):
+        """shard = (rank, world): strong scaling -- the batch of B utterances is generated as a whole and this rank keeps
+        the utterances waterfall_amd.dist.shard_batch deals it (round robin over the length-sorted order)."""
         w = WORKLOADS[name]
-        self.name, self.B, self.T, self.dev = name, B, T, dev
+        self.name, self.T, self.dev = name, T, dev
         P, L = w["P"], w["L"]
         rng = np.random.default_rng(seed)
         phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
         lazy = wf.Topology(w["topo"], phones)
         self.V = V = lazy.num_nn_output
         self.seqs = [[int(x) + 2 for x in rng.integers(0, P, size=L)] for _ in range(B)]
-        if w["den"]:
-            self.fsa = wf.create_fsa_vec([lazy.fsa] * B)
-        else:
-            self.fsa = wf.compile_ctc_k2_graphs(lazy, self.seqs)
         lens = np.full(B, T)
         if ragged:
             lens = np.sort(rng.integers(int(0.7 * T), T + 1, size=B))[::-1].copy()
             lens[0] = T
-        self.segs = np.stack([np.arange(B), np.zeros(B, dtype=np.int64), lens], 1).astype(np.int32)
         g = torch.Generator(device=dev).manual_seed(seed)
-        self.lp = torch.log_softmax(torch.randn(B, T, V, generator=g, device=dev) * 3.0, -1)
+        keep = None
+        if shard is not None:
+            keep = np.sort(wf.dist.shard_batch(lens, shard[1], shard[0]))
+            self.seqs = [self.seqs[i] for i in keep]
+            lens = lens[keep]
+            full = torch.randn(B, T, V, generator=g, device=dev)
+            self.lp = torch.log_softmax(full[torch.from_numpy(keep).to(dev)] * 3.0, -1)
+            del full
+            B = len(keep)
+        else:
+            self.lp = torch.log_softmax(torch.randn(B, T, V, generator=g, device=dev) * 3.0, -1)
+        self.B = B
+        if w["den"]:
+            self.fsa = wf.create_fsa_vec([lazy.fsa] * B)
+        else:
+            self.fsa = wf.compile_ctc_k2_graphs(lazy, self.seqs)
+        self.segs = np.stack([np.arange(B), np.zeros(B, dtype=np.int64), lens], 1).astype(np.int32)
         self.grad = torch.empty_like(self.lp)
         self.tot = torch.empty(B, dtype=torch.float32, device=dev)
         self.gscale = torch.full((B,), -1.0, dtype=torch.float32, device=dev)
@@ -158,21 +196,30 @@ class Workload:
         return {"gather": gather, "sweep": sweep, "post": post, "zero": zero, "check": check, "path_survey_8d": path}
 
 
-def time_steps(wl, steps, warmup, dist, stream, fused_buf):
+def time_steps(wl, steps, warmup, dist, stream, fused_buf, min_region_s=0.0, max_rounds=200):
+    """Times EXACTLY `steps` steps between (barrier + synchronize) brackets, and repeats that timed region until the
+    regions add up to min_region_s (a 2.7 ms region is at the mercy of one scheduling hiccup).  Returns the list of the
+    regions' durations in seconds (every rank runs the same number of regions: the count is agreed on after the first)."""
     bufs = [fused_buf, fused_buf.clone()]
     works = [None, None]
     count = [0]
+    with_grad = fused_buf.numel() > 3
 
     def one():
         wl.step(stream)
         if dist is not None:
-            # single fused all-reduce per step: [loss_sum, n_frames, n_infeasible], started asynchronously on one of two
-            # buffers so that it overlaps the next step's sweeps (logging data: nothing on the data path waits for it)
+            # single fused all-reduce per step: [loss_sum, n_frames, n_infeasible (, per-label gradient sums)], started
+            # asynchronously on one of two buffers so that it overlaps the next step's sweeps (logging data: nothing on
+            # the data path waits for it)
             j = count[0] & 1
             count[0] += 1
             if works[j] is not None:
                 works[j].wait()
-            _, works[j] = wf.dist.fused_loss_stats(wl.tot, wl.frames, out=bufs[j], async_op=True)
+            if os.environ.get("WF_BENCH_SYNC_ALLREDUCE"):   # (diagnostic: the collective on the launch stream)
+                wf.dist.fused_loss_stats(wl.tot, wl.frames, out=bufs[j], grad=wl.grad if with_grad else None)
+                return
+            _, works[j] = wf.dist.fused_loss_stats(wl.tot, wl.frames, out=bufs[j], async_op=True,
+                                                   grad=wl.grad if with_grad else None)
 
     def drain():
         for j in (0, 1):
@@ -180,20 +227,39 @@ def time_steps(wl, steps, warmup, dist, stream, fused_buf):
                 works[j].wait()
                 works[j] = None
 
+    def region():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        drain()          # every step's all-reduce is inside the timed region
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    dbg = bool(os.environ.get("WF_BENCH_DEBUG"))
+    if dbg:
+        import faulthandler
+        faulthandler.dump_traceback_later(40, exit=False, file=sys.stderr)
     for _ in range(warmup):
         one()
     drain()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    drain()          # every step's all-reduce is inside the timed region
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0
+    if dbg:
+        print("warmup done", file=sys.stderr, flush=True)
+    times = [region()]
+    if dbg:
+        print("first region", times, file=sys.stderr, flush=True)
+    rounds = int(min(max_rounds, max(1, np.ceil(min_region_s / max(times[0], 1e-6)))))
+    if dist is not None:   # the same number of regions on every rank
+        r = torch.tensor([rounds], dtype=torch.int64, device=wl.lp.device)
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        rounds = int(r.item())
+    for _ in range(rounds - 1):
+        times.append(region())
+    return times
 
 
 def kernel_times(wl, stream, reps=20):
@@ -418,6 +484,15 @@ def main():
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = --batch utterances per GPU; strong = --batch utterances in all, dealt over the ranks "
+                         "(BASELINE.json configs[2] is B=32 sharded over 8 GPUs)")
+    ap.add_argument("--grad-sums", action="store_true",
+                    help="N > 1: append the V per-label gradient sums (wf_label_grad_sums) to the fused all-reduce buffer. Off by "
+                         "default so that the N > 1 step is the N = 1 step plus the collective (the driver computes scaling "
+                         "efficiency from the two); the kernel's cost is reported at N = 1 as label_grad_sums_ms")
+    ap.add_argument("--min-region-ms", type=float, default=100.0,
+                    help="repeat the timed K-step region until the regions add up to this (median and min are reported)")
     ap.add_argument("--others", action="store_true", help="(default at N=1) also time the other BASELINE workloads")
     ap.add_argument("--no-others", action="store_true", help="headline only")
     args = ap.parse_args()
@@ -435,17 +510,33 @@ def main():
         else:
             dist.init_process_group(backend)
             local = local % max(torch.cuda.device_count(), 1)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} but the job has {dist.get_world_size()} ranks")
+        if dist.get_backend() != backend:
+            raise SystemExit(f"process group backend is {dist.get_backend()}, expected {backend}")
+    elif args.gpus != 1:
+        raise SystemExit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    wl = Workload(args.workload, args.batch, args.frames, dev, seed=777 + rank, ragged=args.ragged)
-    fused = torch.zeros(3, dtype=torch.float32, device=dev)
-    dt = time_steps(wl, args.steps, args.warmup, dist, stream, fused)
+    strong = world > 1 and args.scaling == "strong"
+    if strong:
+        if args.batch < world:
+            raise SystemExit(f"--scaling strong: {args.batch} utterances cannot be dealt over {world} ranks")
+        wl = Workload(args.workload, args.batch, args.frames, dev, seed=777, ragged=args.ragged, shard=(rank, world))
+    else:
+        wl = Workload(args.workload, args.batch, args.frames, dev, seed=777 + rank, ragged=args.ragged)
+    grad_sums = world > 1 and args.grad_sums
+    fused = torch.zeros(3 + (wl.V if grad_sums else 0), dtype=torch.float32, device=dev)
+    times = time_steps(wl, args.steps, args.warmup, dist, stream, fused, min_region_s=args.min_region_ms * 1e-3)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        t = torch.tensor(times, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # every region: the slowest rank's time
+        times = t.tolist()
+    dt = float(np.median(times))
+    dt_min = float(np.min(times))
+    if dist is not None:
         tf = torch.tensor([float(wl.frames), float(wl.arc_updates)], dtype=torch.float64, device=dev)
         dist.all_reduce(tf)
         total_frames, total_arcs = tf[0].item(), tf[1].item()
@@ -457,13 +548,22 @@ def main():
     out = {
         "metric": "DWFST loss+grad utterance-frames/sec",
         "value": value, "unit": "utterance-frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}, B={args.batch} per GPU, "
-                               f"T={args.frames}{' ragged' if args.ragged else ''}, loss+grad, reduction=sum, exact (no output_beam pruning)",
-                   "batch_per_gpu": args.batch, "frames": args.frames, "V": wl.V,
+        "timed_regions": len(times), "timed_region_ms_total": sum(times) * 1e3,
+        "ms_per_step_min": dt_min / args.steps * 1e3, "value_at_min": total_frames / (dt_min / args.steps),
+        "statistic": f"median over {len(times)} timed regions of exactly {args.steps} steps each (value, ms_per_step); "
+                     "the fastest region alongside (value_at_min, ms_per_step_min)",
+        "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}, "
+                               + (f"B={args.batch} in all, dealt over {world} GPUs, " if strong else f"B={args.batch} per GPU, ")
+                               + f"T={args.frames}{' ragged' if args.ragged else ''}, loss+grad, reduction=sum, exact (no output_beam pruning)",
+                   "scaling": "strong" if strong else "weak",
+                   "batch_per_gpu": wl.B, "batch_total": args.batch if (strong or world == 1) else args.batch * world,
+                   "frames": args.frames, "V": wl.V,
                    "states_per_graph": wl.S_mean, "arcs_per_graph": wl.A_mean,
-                   "parallelism": f"batch-sharded x{world}, one fused all-reduce per step" if world > 1 else "single GPU"},
+                   "parallelism": (f"batch-sharded x{world}, one fused all-reduce per step of [loss_sum, n_frames, n_infeasible"
+                                   + (f", {wl.V} per-label gradient sums]" if grad_sums else "]")) if world > 1 else "single GPU"},
         "arc_updates_per_sec": 2 * total_arcs / (dt / args.steps),
     }
     if rank == 0:
@@ -479,23 +579,45 @@ def main():
             kname = {"sweep": "sweep_linbig_kernel", "post": "post_big_kernel"}.get(dom, KERNEL_NAMES.get(dom, dom))
         else:
             kname = dom + " (kernel picked by graph size: DESIGN.md section 4)"
+        rp_us = rocprof_avg_us(dom, default_wl)
         out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, default_wl),
                            "avg_launch_ms": kt[dom], "algorithmic_bytes_per_launch": kb[dom],
-                           "rocprof_avg_launch_us": rocprof_avg_us(dom, default_wl),
+                           "convention": "achieved / frac: algorithmic bytes / the HIP-event interval measured in this run "
+                                         "(avg_launch_ms); *_rocprof: the same bytes / the kernel's average duration in the "
+                                         "committed rocprofv3 summary, null when that summary is of another kernel source",
+                           "rocprof_avg_launch_us": rp_us,
+                           "achieved_rocprof": kb[dom] / (rp_us * 1e-6) / 1e9 if rp_us else None,
+                           "frac_rocprof": kb[dom] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS if rp_us else None,
+                           "profiles_match_kernel_source": profiles_current(),
+                           "kernel_source_sha256": kernel_source_hash(),
                            "note": "dominant kernel by duration. The alpha/beta sweep is dependency-latency bound (T "
                                    "sequential frame steps; kernels.sweep.us_per_frame_step is its figure of merit); the "
                                    "only bandwidth-bound kernel is the gradient zero-fill, which runs beside the sweep on "
                                    "a side stream (kernels.zero). avg_launch_ms is the HIP-event interval around the launch on its "
                                    "stream (it includes the launch / event latency and, for the sweep, the fork of the fill: "
                                    "~7 us more than the kernel's own duration in the committed rocprofv3 summary, "
-                                   "rocprof_avg_launch_us). traffic: profiles/r01d_pmc_traffic.json"}
+                                   "rocprof_avg_launch_us). traffic: profiles/" + PROFILE_TAG + "_pmc_traffic.json"}
         out["kernels"] = {k: {"avg_ms": kt[k], "algorithmic_bytes": kb[k],
                               "GBps": kb[k] / (kt[k] * 1e-3) / 1e9 if kt[k] > 0 else None} for k in kt}
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
         out["path_GBps_survey_8d"] = kb["path_survey_8d"] / (ms_step * 1e-3) / 1e9
         if world == 1:
+            try:   # the optional tail of the fused all-reduce buffer: its kernel, timed here
+                buf = torch.zeros(3 + wl.V, dtype=torch.float32, device=dev)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                wf.dist.fused_loss_stats(wl.tot, wl.frames, out=buf, grad=wl.grad)
+                ev[0].record()
+                for _ in range(10):
+                    wf.dist.fused_loss_stats(wl.tot, wl.frames, out=buf, grad=wl.grad)
+                ev[1].record()
+                torch.cuda.synchronize()
+                ref = wl.grad.reshape(-1, wl.V).double().sum(0)
+                out["label_grad_sums_ms"] = ev[0].elapsed_time(ev[1]) / 10
+                out["label_grad_sums_max_abs_err"] = float((buf[3:].double() - ref).abs().max().item())
+            except Exception as e:   # noqa: BLE001
+                out["label_grad_sums_ms"] = {"error": repr(e)}
             try:
                 out.update(dropin_times(wl, max(20, args.steps)))
             except Exception as e:   # noqa: BLE001
@@ -514,8 +636,8 @@ def main():
                 try:
                     B = 32
                     w2 = Workload(name, B, args.frames, dev, seed=777)
-                    d2 = time_steps(w2, max(5, args.steps // 5), 3, None, stream, fused)
                     n2 = max(5, args.steps // 5)
+                    d2 = float(np.median(time_steps(w2, n2, 3, None, stream, fused[:3], min_region_s=0.03)))
                     k2 = kernel_times(w2, stream, reps=5)
                     others[name] = {"frames_per_s": w2.frames / (d2 / n2), "ms_per_step": d2 / n2 * 1e3,
                                     "arc_updates_per_sec": 2 * w2.arc_updates / (d2 / n2), "kernels_ms": k2,

@@ -272,6 +272,11 @@ int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2
  * from Lightning's DDP reductions around graph.py:66-76).  out[0] = -(sum of the finite tot[i]), out[1] = n_frames,
  * out[2] = number of infeasible utterances (tot = -inf); device pointers, one small launch on `stream`.            */
 int wf_loss_stats(const float* tot, int32_t B, float n_frames, float* out, void* stream);
+/* The optional tail of that buffer: out[v] = sum over n < num_seqs, t < Tmax of grad[n, t, v], v < V --
+ * the per-label gradient sums a training loop logs.  grad: the box wf_fb_logsum filled (element (n, t, v) at
+ * n*strideB + t*strideT + v); out: device fp32 [V]; one streaming pass over the box on `stream`.                       */
+int wf_label_grad_sums(const float* grad, int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t Tmax, int32_t V,
+                       float* out, void* stream);
 
 /* ---- measurement aid (no counterpart in the reference) ------------------------------------------
  * wf_timing_enable(1): the following wf_fb_logsum / wf_fb_backward calls of this host thread record

@@ -1066,3 +1066,17 @@ def test_hub_form_denominators(topo, path):
         T = int(c["segs"][b, 2])
         np.testing.assert_allclose(grad[b, :T].sum(-1), -1.0, atol=2e-3)
         assert np.all(grad[b, T:] == 0)
+
+
+def test_label_grad_sums_kernel_matches_torch():
+    """wf_label_grad_sums (the optional tail of the fused all-reduce buffer) on a strided gradient box."""
+    from waterfall_amd.dist import fused_loss_stats
+    g = torch.Generator().manual_seed(12)
+    for N, T, V in ((3, 17, 5), (2, 90, 1025), (5, 41, 5001)):
+        big = torch.randn(N, T + 3, V, generator=g).to(DEV)
+        grad = big[:, 1:T + 1]                      # a view: rows strided, columns contiguous
+        tot = torch.tensor([-1.0, -2.5, float("-inf")][:min(N, 3)], device=DEV)
+        out = fused_loss_stats(tot, 77, grad=grad).cpu().numpy()
+        ref = grad.double().sum((0, 1)).cpu().numpy()
+        np.testing.assert_allclose(out[3:], ref, rtol=1e-4, atol=1e-4)
+        assert out[1] == 77

@@ -45,6 +45,7 @@ _SIGS = {
     "wf_compose_linear": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, C.POINTER(_i32), C.POINTER(_i32), _i32]),
     "wf_compose_fsa_batch": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, C.c_int64, _p, _p]),
     "wf_loss_stats": (C.c_int, [_p, _i32, C.c_float, _p, _p]),
+    "wf_label_grad_sums": (C.c_int, [_p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
     "wf_topo_index_words": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(C.c_int64)]),
     "wf_topo_index_build": (C.c_int, [_p, _p, _i32, _i32, _p]),
     "wf_compose_linear_batch": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _i32, _p, _p, C.c_int64, _p, _p]),

@@ -5251,6 +5251,38 @@ extern "C" int wf_loss_stats(const float* tot, int32_t B, float n_frames, float*
     return WF_OK;
 }
 
+// Per-label column sums of a gradient box grad[n, t, :] (n < N, t < T): the tail of the fused all-reduce buffer
+// ([loss_sum, n_frames, n_infeasible, sum_{b,t} grad[b,t,label]]).  A streaming read of the box: a
+// workgroup owns 1024 columns (4 per lane, 256 apart: coalesced) over a run of kLabelRows rows and adds its partial sums
+// into out[] with one atomic per column.  Rows outside the segments hold zeros by wf_fb_logsum's contract.
+constexpr int kLabelRows = 40;
+__global__ void __launch_bounds__(256) label_sums_kernel(const float* grad, int64_t strideB, int64_t strideT, int N, int T,
+                                                          int V, float* out) {
+    const int c0 = blockIdx.x * 1024 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * kLabelRows, r1 = min(r0 + kLabelRows, (int64_t)N * T);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0; r < r1; ++r) {
+        const float* row = grad + (r / T) * strideB + (r % T) * strideT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = c0 + j * 256; if (c < V) acc[j] += row[c]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = c0 + j * 256; if (c < V && acc[j] != 0.f) atomicAdd(out + c, acc[j]); }
+}
+
+extern "C" int wf_label_grad_sums(const float* grad, int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t Tmax,
+                                  int32_t V, float* out, void* stream) {
+    if (!grad || !out || num_seqs < 0 || Tmax < 0 || V < 1) return wf_fail(WF_EINVAL, "wf_label_grad_sums: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)V, st));
+    const int64_t rows = (int64_t)num_seqs * Tmax;
+    if (rows == 0) return WF_OK;
+    const dim3 grid((V + 1023) / 1024, (unsigned)((rows + kLabelRows - 1) / kLabelRows));
+    hipLaunchKernelGGL(label_sums_kernel, grid, dim3(256), 0, st, grad, strideB, strideT, num_seqs, Tmax, V, out);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
 // ---- the drop-in's eager gradient (waterfall_amd/graph.py): loss reduction and upstream-gradient scaling ----------
 // loss_reduce_kernel: out[0] = sum_b w[b] * (-tot[b]) (w == NULL: 1), one workgroup.  graph.py:66-76's reductions
 // ('sum'; 'mean' with w[b] = 1 / (B * target_lengths[b])) without three elementwise torch launches.

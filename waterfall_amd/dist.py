@@ -66,7 +66,15 @@ def fused_loss_stats(tot, n_frames, group=None, grad=None, out=None, async_op=Fa
         out[0] = -torch.where(ok, tot, torch.zeros_like(tot)).sum()
         out[1] = float(n_frames)
         out[2] = (~ok).sum()
-    if V:
+    if V and grad.device.type == "cuda" and grad.dtype == torch.float32 and grad.dim() == 3 and grad.stride(2) == 1:
+        # one streaming kernel straight into the tail of the buffer (no [B*T, V] torch reduction, no temporary)
+        import ctypes as C
+        from . import _lib
+        with torch.cuda.device(grad.device):
+            _lib.check(_lib.lib().wf_label_grad_sums(C.c_void_p(grad.data_ptr()), grad.stride(0), grad.stride(1),
+                                                     grad.shape[0], grad.shape[1], V, C.c_void_p(out[3:].data_ptr()),
+                                                     C.c_void_p(torch.cuda.current_stream(grad.device).cuda_stream)))
+    elif V:
         out[3:] = grad.reshape(-1, V).sum(0)
     work = None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
