@@ -112,7 +112,13 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
     for (int j = 0; j < A; ++j) { const int l = arcs[4 * (size_t)X.em[j] + 2]; X.col[j] = direct ? l : X.colmap[l]; }
     *out_maxlab = max_label;
 
-    auto take = [&](size_t n) { size_t o = cur; cur += pad4(n); return (int32_t)o; };
+    // (the padding words of a table are zeroed: the blob is a pure function of the graph, never a copy of stale memory)
+    auto take = [&](size_t n) {
+        size_t o = cur;
+        cur += pad4(n);
+        if (cur <= limit) for (size_t i = o + n; i < cur; ++i) B[i] = 0;
+        return (int32_t)o;
+    };
     memset(I, 0, sizeof(int32_t) * WF_INFO_WORDS);
     I[WF_I_S] = S; I[WF_I_A] = A; I[WF_I_NF] = NF; I[WF_I_K] = K; I[WF_I_DIRECT] = direct;
     I[WF_I_ARC_BASE] = a0;
@@ -149,6 +155,7 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
             if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s2;
             if (deg > WF_REG_DEG) { ++nover; over = s2; }
         }
+        std::fill(B + o_h + nh, B + o_h + S, 0);
         I[WF_I_HEAVY_IN] = o_h; I[WF_I_NHEAVY_IN] = nh; I[WF_I_MAXIN] = maxin;
         I[WF_I_NOVER_IN] = nover; I[WF_I_OVER_IN] = over;
     }
@@ -178,6 +185,7 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
             if (deg > WF_HEAVY_DEG) B[o_h + nh++] = s2;
             if (deg > WF_REG_DEG) { ++nover; over = s2; }
         }
+        std::fill(B + o_h + nh, B + o_h + S, 0);
         I[WF_I_HEAVY_OUT] = o_h; I[WF_I_NHEAVY_OUT] = nh; I[WF_I_MAXOUT] = maxout;
         I[WF_I_NOVER_OUT] = nover; I[WF_I_OVER_OUT] = over;
     }
