@@ -49,6 +49,24 @@ GENERATORS = {
 }
 
 
+# deprecated/get_token_fst_*_blk_k2.py: run on a phones.txt WITH disambiguation symbols (they print a self-loop per '#k')
+DEPRECATED_GENERATORS = {"2state_blk": "get_token_fst_2state_blk_k2.py", "mmictc_blk": "get_token_fst_mmictc_blk_k2.py"}
+PHONES_DISAMBIG = PHONES + ["#0", "#1"]
+
+
+def make_deprecated_topologies():
+    pf = os.path.join(HERE, "phones_disambig.txt")
+    with open(pf, "w") as f:
+        for i, p in enumerate(PHONES_DISAMBIG):
+            f.write(f"{p} {i}\n")
+    for name, script in DEPRECATED_GENERATORS.items():
+        out = subprocess.run([sys.executable, os.path.join(REF, "deprecated", script), pf],
+                             check=True, capture_output=True, text=True).stdout
+        with open(os.path.join(HERE, f"topo_{name}.txt"), "w") as f:
+            f.write(out)
+        print("deprecated topology", name, len(out.splitlines()), "lines")
+
+
 def make_topologies():
     pf = os.path.join(HERE, "phones_k2.txt")
     with open(pf, "w") as f:
@@ -179,6 +197,7 @@ def make_topo_case(seed, topo_name, B, T, Lmax, name, phones=None, Lmin=1, eta=N
 
 if __name__ == "__main__":
     make_topologies()
+    make_deprecated_topologies()
     make_ctc_case(777, B=4, T=24, V=6, Lmax=5, name="manual_ctc_ctc_small.npz")
     make_ctc_case(778, B=3, T=60, V=12, Lmax=12, name="manual_ctc_ctc_medium.npz")
     for i, tn in enumerate(["2state", "2state-1", "3state-skip", "3state-skip-1", "3state-skip-2", "mmictc",

@@ -24,6 +24,16 @@ def test_topology_text_equals_reference_generator_output(name):
     assert norm(got) == norm(want)
 
 
+@pytest.mark.parametrize("name", ["2state_blk", "mmictc_blk"])
+def test_deprecated_blk_topology_text_equals_reference_generator_output(name):
+    # deprecated/get_token_fst_{2state,mmictc}_blk_k2.py run on a phones.txt with disambiguation symbols (make_golden.py)
+    phones = [l.split()[0] for l in open(os.path.join(util.GOLDEN, "phones_disambig.txt"))]
+    want = open(os.path.join(util.GOLDEN, f"topo_{name}.txt")).read().split("\n")
+    got = wf.topology_text(name, phones).split("\n")
+    norm = lambda ls: [" ".join(l.split()) for l in ls if l.strip()]
+    assert norm(got) == norm(want)
+
+
 @pytest.mark.parametrize("name,S,A", [("ctc", lambda P: 1 + P, lambda P: 1 + 3 * P + P * (P - 1)),
                                       ("2state", lambda P: 1 + 2 * P, lambda P: 1 + 6 * P),
                                       ("2state-1", lambda P: 1 + 2 * P, lambda P: 1 + 5 * P),

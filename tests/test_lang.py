@@ -23,8 +23,7 @@ def test_lang_dir_round_trip(tmp_path, topo):
     assert lang.words[0] == "<eps>" and lang.phones[0] == "<eps>" and lang.phones[-1] == "#0"
     yes, no = lang.word2idx["YES"], lang.word2idx["NO"]
     assert lang.get_pids_list_from_wids_list([[yes, no]]) == [[lang.phone2idx[p] for p in "YESNO"]]
-    with pytest.raises(NotImplementedError):
-        lang.load_lexicon()
+    assert lang.load_lexicon() is None          # neither k2/L_inv.pt nor L.fst.txt: the align lexicon stands in
 
 
 def _yesno_batch(tmp_path, seed=777, B=8, T=100):
@@ -161,3 +160,75 @@ def test_word_level_numerators_on_the_gpu(tmp_path):
     best = wf.best_path(graphs, wf.DenseFsaVec(x.detach(), torch.from_numpy(segs)))
     # the aux labels along the best path spell the word sequence
     assert best["aux_labels"] == wids
+
+
+# ---- the default route of compile_training_graph is the reference's (datapipe.py:233-256): every pronunciation, L.fst's
+# ---- optional silences.  k2's arc weights after remove_epsilon / its numbering: parity unpinned (no k2 here). ---------
+
+def _weighted_language(g):
+    """phone string -> log-sum of the scores of its paths (acyclic oracle graph)."""
+    out_arcs = {}
+    for s, d, l, w in zip(g["src"], g["dst"], g["label"], g["score"]):
+        out_arcs.setdefault(int(s), []).append((int(d), int(l), float(w)))
+    res, stack = {}, [(0, (), 0.0)]
+    while stack:
+        s, pre, w = stack.pop()
+        for d, l, x in out_arcs.get(s, []):
+            if l < 0:
+                res[pre] = np.logaddexp(res.get(pre, -np.inf), w + x)
+            else:
+                stack.append((d, pre + (l,), w + x))
+    return res
+
+
+def test_default_training_graph_has_every_pronunciation_and_the_optional_silence(tmp_path):
+    d = wf.write_lang_dir(str(tmp_path / "a"), LEX_VARIANTS, YESNO_PHONES, "2state_sil", optional_silence="<SIL>")
+    lang = wf.Lang(d, load_topo=True)
+    wids = [[lang.word2idx["YES"], lang.word2idx["NO"]], [lang.word2idx["O"]]]
+    got = lang.compile_training_graph(wids)                                   # no arguments: the reference's call
+    want = wf.compose(lang.topo, lang.word_graphs(wids, "<SIL>", 0.5))
+    assert np.array_equal(got.arcs, want.arcs) and np.array_equal(got.aux_labels, want.aux_labels)
+    # the old short cut (last pronunciation only, no silence) is a strictly narrower graph
+    narrow = wf.compile_ctc_k2_graphs(lang.topo, lang.get_pids_list_from_wids_list(wids))
+    assert got.fsa_num_states[0] > narrow.fsa_num_states[0]
+    # variants but no optional silence in the lang dir: still both pronunciations
+    d2 = wf.write_lang_dir(str(tmp_path / "b"), LEX_VARIANTS, YESNO_PHONES, "ctc")
+    lang2 = wf.Lang(d2, load_topo=True)
+    P = lang2.phone2idx
+    bg = lang2.word_graphs([[lang2.word2idx["YES"]]], None).as_oracle_graphs()[0]
+    assert _accepted_strings(bg) == {(P["Y"], P["E"], P["S"]), (P["Y"], P["E"])}
+    g2 = lang2.compile_training_graph([[lang2.word2idx["YES"]]])
+    w2 = wf.compose(lang2.topo, lang2.word_graphs([[lang2.word2idx["YES"]]], None))
+    assert np.array_equal(g2.arcs, w2.arcs)
+    # one pronunciation per word and no silence: the linear route, identical graphs
+    g3 = lang2.compile_training_graph([[lang2.word2idx["NO"], lang2.word2idx["O"]]])
+    w3 = wf.compile_ctc_k2_graphs(lang2.topo, [[P["N"], P["O"], P["O"]]])
+    assert np.array_equal(g3.arcs, w3.arcs) and np.array_equal(g3.fsa_num_states, w3.fsa_num_states)
+
+
+def test_lexicon_transducer_route_equals_the_align_lexicon_route(tmp_path):
+    """load_lexicon (L.fst.txt, then the k2/L_inv.pt dict) + intersect / invert / remove_epsilon on the host against the
+    graphs built straight from the align lexicon: the same weighted set of phone strings per utterance."""
+    d = wf.write_lang_dir(str(tmp_path), LEX_VARIANTS, YESNO_PHONES, "2state_sil", optional_silence="<SIL>", sil_prob=0.3,
+                          write_L=True)
+    lang = wf.Lang(d, load_topo=True, load_lexicon=True)
+    assert lang.L is not None and lang.L_inv is not None
+    names = ["YES", "NO", "O"]
+    wids = [[lang.word2idx[n] for n in ws] for ws in (["YES", "NO"], ["O"], ["NO", "O", "YES"], [])]
+    via_L = lang._lexicon_graphs(wids).as_oracle_graphs()
+    direct = lang.word_graphs(wids, "<SIL>", 0.3).as_oracle_graphs()
+    for a, b, ws in zip(via_L, direct, wids):
+        la, lb = _weighted_language(a), _weighted_language(b)
+        assert set(la) == set(lb) and len(la) >= 2
+        for k in la:
+            np.testing.assert_allclose(la[k], lb[k], atol=1e-5)
+        assert {int(x) for x in a["aux"] if x > 0} == {int(x) for x in b["aux"] if x > 0} == set(ws)
+    g = lang.compile_training_graph(wids)                 # default: the loaded transducer's route
+    assert g.num_fsas == 4
+    # the L_inv.pt dict layout (torch.save(L_inv.as_dict()), datapipe.py:204), weights-only
+    torch.save({"arcs": torch.from_numpy(lang.L_inv.arcs.copy()), "aux_labels": torch.from_numpy(lang.L_inv.aux_labels.copy())},
+               str(tmp_path / "k2" / "L_inv.pt"))
+    again = wf.Lang(d, load_topo=True, load_lexicon=True)
+    assert np.array_equal(again.L_inv.arcs, lang.L_inv.arcs) and np.array_equal(again.L.aux_labels, lang.L.aux_labels)
+    for a, b in zip(again._lexicon_graphs(wids).as_oracle_graphs(), via_L):
+        assert np.array_equal(a["label"], b["label"]) and np.array_equal(a["score"], b["score"])

@@ -188,9 +188,38 @@ TOPOLOGIES = {
 }
 
 
+def _arcs_blk(phones, mmictc):
+    """deprecated/get_token_fst_2state_blk_k2.py:19-37 and deprecated/get_token_fst_mmictc_blk_k2.py:20-39: the 2state /
+    mmictc arcs for EVERY phone of a phones.txt that still holds the disambiguation symbols (<SIL> is an ordinary phone
+    here), plus a self-loop '#k : #k' on state 0 per disambiguation symbol (for decoding-graph construction)."""
+    arcs = [(0, 0, BLK, EPS)]
+    x = 1
+    for p in phones:
+        if p in (EPS, BLK):
+            continue
+        if p.startswith("#"):
+            arcs.append((0, 0, p, p))
+        elif mmictc:
+            arcs += [(0, 0, p + "_0", p), (0, x, p + "_0", p), (x, 0, p + "_1", EPS), (x, x + 1, p + "_1", EPS),
+                     (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_1", EPS)]
+        else:
+            arcs += [(0, x, p + "_0", p), (x, 0, p + "_1", EPS), (x, x, p + "_0", EPS), (x, x + 1, p + "_1", EPS),
+                     (x + 1, x + 1, p + "_1", EPS), (x + 1, 0, p + "_1", EPS)]
+        x += 2           # (the generators advance the state counter for disambiguation symbols too)
+    return arcs, [0]
+
+
+# The reference keeps these two generators under deprecated/: available as text (topology_text) for building decoding
+# graphs with disambiguation symbols, not as training topologies (no tokens table of their own in the recipes).
+DEPRECATED_TOPOLOGIES = {
+    "2state_blk": lambda ph: _arcs_blk(ph, False),
+    "mmictc_blk": lambda ph: _arcs_blk(ph, True),
+}
+
+
 def topology_text(name, phones):
     """The OpenFst text the reference generator prints (symbolic labels), one arc per line."""
-    arcs, finals = TOPOLOGIES[name][0](phones)
+    arcs, finals = (TOPOLOGIES[name][0] if name in TOPOLOGIES else DEPRECATED_TOPOLOGIES[name])(phones)
     lines = ["%d %d %s %s" % a for a in arcs] + ["%d" % f for f in finals]
     return "\n".join(lines) + "\n"
 
