@@ -1534,8 +1534,8 @@ constexpr HubPattern kHubPatterns[] = {
 };
 constexpr int kHubNumPatterns = 5;
 
-// the G values of one group as one store (rows are 8-byte aligned; the groups start at state 1)
-template <int G> struct __attribute__((packed, aligned(8))) HubRow { double v[G]; };
+// the G values of one group as one store (rows are 4-byte aligned; the groups start at state 1)
+template <int G> struct __attribute__((packed, aligned(4))) HubRow { float v[G]; };
 
 // PAT: index into kHubPatterns (G = 2), or -1: the pattern is only known at run time.
 template <int G, int NC, int PAT>
@@ -1630,7 +1630,10 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) c0[c] = uni(c0p[c]);
     const int nslot = (NG + kHubCompute - 1) / kHubCompute;
-    double* arena = (double*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
+    // Rows leave as fp32 (same element offsets as the fp64 arenas of the other sweeps: the first half of the region): the
+    // values of a row are kept within [2^-64, 2^16) of 1 by the per-frame shift, states more than 2^-126 below the row's
+    // maximum are lost to fp32 -- a row that loses mass that way fails the row check and the utterance is redone.
+    float* arena = (float*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
     double* goff = (dir ? p.boff : p.aoff) + uni(U[WF_U_OFFS]);
     const float finw = __builtin_bit_cast(float, uni(I[WF_I_HUB_FINW]));
     const int xc = NX > 0 ? xcol[min(tid, NX - 1)] : 0;
@@ -1643,8 +1646,8 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
         for (int i = 0; i < G; ++i) a[k][i] = 0.0;
     double h = dir ? exp((double)finw) : 1.0;
     {
-        double* row = arena + (int64_t)(dir ? T : 0) * S;
-        for (int s2 = tid; s2 < S; s2 += kHubCompute) row[s2] = s2 == 0 ? h : 0.0;
+        float* row = arena + (int64_t)(dir ? T : 0) * S;
+        for (int s2 = tid; s2 < S; s2 += kHubCompute) row[s2] = s2 == 0 ? (float)h : 0.f;
         if (tid == 0) goff[0] = 0.0;
         if (dir == 0) {   // c_t = 0 for the kernels that read the per-frame normaliser
             double* crow = p.cmax_w + uni(U[WF_U_ROW0]);
@@ -1673,7 +1676,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             const float* pc = pbuf + (size_t)ib * kp;
             ib = ib + 1 == nb ? 0 : ib + 1;
             const int f = TR ? T - 1 - step : step;
-            double* srow = arena + (int64_t)(TR ? f : f + 1) * S;
+            float* srow = arena + (int64_t)(TR ? f : f + 1) * S;
             cum += (double)sh;
             if (tid == 0) goff[step + 1] = cum;
             double part = 0.0;      // this lane's share of the hub's new value
@@ -1740,7 +1743,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
                     if (g < NG && !(p.ablate & 1)) {   // (ablate: timing aid)
                         HubRow<G> v;
 #pragma unroll
-                        for (int i = 0; i < G; ++i) v.v[i] = nv[i];
+                        for (int i = 0; i < G; ++i) v.v[i] = (float)nv[i];
                         *(HubRow<G>*)(srow + 1 + g * G) = v;
                     }
                 }
@@ -1764,8 +1767,8 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             em = max(em, max(max(ex[8], ex[9]), max(ex[10], ex[11])));
             h = hn;
             em = max(em, f64_exp_field(hn));
-            sh = uni(em > 0 ? (1023 + kLinBias) - em : 0);   // next row: maximum back to 2^kLinBias
-            if (tid == 0) srow[0] = hn;
+            sh = uni(em > 0 ? 1023 - em : 0);   // next row: maximum back to [1, 2)
+            if (tid == 0) srow[0] = (float)hn;
         }
     };
     if (dir) frames(std::true_type{}); else frames(std::false_type{});
@@ -2158,6 +2161,7 @@ struct CheckArgs {
     int32_t* flag;
     int grp, lag;   // frames per rescale group of the sweep that wrote the rows; see lin_shift_index
     int force;      // test hook (WF_FORCE_FALLBACK): flag every utterance
+    int rows_f32;   // the rows are fp32 (hub sweep), not fp64
 };
 
 // log2 of a non-negative double as (integer part exactly, fraction in fp32): log2(0) = -inf
@@ -2187,6 +2191,8 @@ __global__ void __launch_bounds__(64) check_kernel(CheckArgs p) {
     }
     const double* abase = p.alpha + U[WF_U_ALPHA];
     const double* bbase = p.beta + U[WF_U_BETA];
+    const float* abase32 = (const float*)p.alpha + U[WF_U_ALPHA];   // rows_f32 (sweep_hub_kernel): fp32 rows, same element offsets
+    const float* bbase32 = (const float*)p.beta + U[WF_U_BETA];
     const double c0 = p.ctot2[u] - tot2;
     double cst[kCheckFR];
     float sum[kCheckFR];
@@ -2203,8 +2209,8 @@ __global__ void __launch_bounds__(64) check_kernel(CheckArgs p) {
 #pragma unroll
         for (int r = 0; r < kCheckFR; ++r) {
             const int64_t row = (int64_t)min(t0 + r, T) * S;
-            a[r] = abase[row + s];
-            b[r] = bbase[row + s];
+            a[r] = p.rows_f32 ? (double)abase32[row + s] : abase[row + s];
+            b[r] = p.rows_f32 ? (double)bbase32[row + s] : bbase[row + s];
         }
 #pragma unroll
         for (int r = 0; r < kCheckFR; ++r) {
@@ -2245,6 +2251,7 @@ struct StatePostArgs {
     float* out;
     int64_t strideB, strideT;
     int Smax, Tmax;
+    int rows_f32;   // linear-domain rows are fp32 (hub sweep)
 };
 
 __global__ void __launch_bounds__(64) state_post_kernel(StatePostArgs p) {
@@ -2262,6 +2269,8 @@ __global__ void __launch_bounds__(64) state_post_kernel(StatePostArgs p) {
     const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)r * S;
     const double* brow = p.beta + U[WF_U_BETA] + (int64_t)r * S;
     const bool lin = p.lin && !p.flag[u];
+    const float* arow32 = (const float*)p.alpha + U[WF_U_ALPHA] + (int64_t)r * S;
+    const float* brow32 = (const float*)p.beta + U[WF_U_BETA] + (int64_t)r * S;
     const double cst = lin ? p.ctot2[u] - p.tot2[u] - p.aoff[U[WF_U_OFFS] + lin_shift_index(r - 1, p.grp, p.lag)] -
                                  p.boff[U[WF_U_OFFS] + lin_shift_index(T - 1 - r, p.grp, p.lag)]
                            : 0.0;
@@ -2271,8 +2280,8 @@ __global__ void __launch_bounds__(64) state_post_kernel(StatePostArgs p) {
             if (lin) {
                 double ea, eb;
                 float fa, fb;
-                log2_split(arow[s], ea, fa);
-                log2_split(brow[s], eb, fb);
+                log2_split(p.rows_f32 ? (double)arow32[s] : arow[s], ea, fa);
+                log2_split(p.rows_f32 ? (double)brow32[s] : brow[s], eb, fb);
                 v = ((float)(ea + eb + cst) + (fa + fb)) * 0.6931471805599453f;
             } else {
                 v = (float)(arow[s] + brow[s] - tot);
@@ -3180,23 +3189,23 @@ __global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
     int c0[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) c0[c] = uni(c0p[c]);
-    const double* arow = p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
-    const double* brow = p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
+    const float* arow = (const float*)p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;      // (sweep_hub_kernel's fp32 rows)
+    const float* brow = (const float*)p.beta + U[WF_U_BETA] + (int64_t)(t + 1) * S;
     const float* erow = p.lp + (int64_t)q * p.strideB + (int64_t)(start + t) * p.strideT;
     const float gs = p.gscale ? p.gscale[u] : 1.f;
     // alpha row t came from forward step t-1, beta row t+1 from backward step T-2-t (one shift per step, c_t = 0)
     const double kk = -tot2 - p.aoff[U[WF_U_OFFS] + lin_shift_index(t - 1, 1, 0)] - p.boff[U[WF_U_OFFS] + lin_shift_index(T - 2 - t, 1, 0)];
-    // alpha^ * beta^ * 2^kk: alpha^ and beta^ sit near 2^800 each, kk near -1600; split the scale over both factors
+    // alpha^ * beta^ * 2^kk with alpha^, beta^ near 1: split the scale over both factors so that neither leaves fp32's range
     const int k1 = (int)floor(kk * 0.5);
-    const double sa = exp2(kk - (double)k1 - (double)k1);   // in [1, 4): the fractional part
-    const double ha = ldexp(arow[0] * sa, k1), hb = ldexp(brow[0], k1);
+    const float sa = (float)exp2(kk - (double)k1 - (double)k1);   // in [1, 4): the fractional part
+    const float ha = ldexpf(arow[0] * sa, k1), hb = ldexpf(brow[0], k1);
     float chk = 0.f;
     for (int g = tid; g < NG; g += 256) {
-        double av[W], bv[W];
+        float av[W], bv[W];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            av[i] = ldexp(arow[1 + g * G + i] * sa, k1);
-            bv[i] = ldexp(brow[1 + g * G + i], k1);
+            av[i] = ldexpf(arow[1 + g * G + i] * sa, k1);
+            bv[i] = ldexpf(brow[1 + g * G + i], k1);
         }
         av[G] = ha; bv[G] = hb;
         float pr[NC], acc[NC];
@@ -3207,7 +3216,7 @@ __global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
 #pragma unroll
             for (int j = 0; j < W; ++j)
                 if (present & (1u << (i * W + j))) {   // arcs j -> i: alpha_t[j] * beta_{t+1}[i]
-                    const float w = (float)(av[j] * bv[i]);
+                    const float w = av[j] * bv[i];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) acc[c] = fmaf(cf[i][j][c], w, acc[c]);
                 }
@@ -3220,7 +3229,7 @@ __global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
     }
     for (int e = tid; e < NX; e += 256) {
         const int col = xcol[e];
-        const float val = (float)(ha * hb) * __builtin_amdgcn_exp2f(erow[col] * kLog2e);
+        const float val = (ha * hb) * __builtin_amdgcn_exp2f(erow[col] * kLog2e);
         chk += val;
         grow[col] = gs * val;
     }
@@ -5076,7 +5085,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
         }
         CheckArgs k{a.blob, a.utt, (const double*)a.alpha, (const double*)a.beta, a.aoff, a.boff, a.tot2, a.ctot2,
                     (int32_t*)(ws + P.off_flag), lgrp, llag,
-                    hk().force_fallback};
+                    hk().force_fallback, P.hub ? 1 : 0};
         hipLaunchKernelGGL(check_kernel, dim3((P.Tlong + 1 + kCheckFR - 1) / kCheckFR, B), dim3(64), 0, st, k);
         HIP_TRY(hipGetLastError());
         rc = launch_sweep<double, float, M_FB>(fc, fa, B, st);
@@ -5431,6 +5440,7 @@ extern "C" int wf_state_posteriors(const void* graph_host, const void* graph_dev
     lin_grp_lag(P, &a.grp, &a.lag);
     if (!P.lin) a.grp = 1;
     a.out = out; a.strideB = out_strideB; a.strideT = out_strideT; a.Smax = Smax; a.Tmax = Tmax;
+    a.rows_f32 = P.hub ? 1 : 0;
     hipLaunchKernelGGL(state_post_kernel, dim3(std::max(Tmax, 1), B), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
