@@ -281,6 +281,7 @@ def kernel_times(wl, stream, reps=20):
         return dict(zip(("gather", "sweep", "post", "zero", "check"), (acc / reps).tolist()))
 
     kt = run()
+    kt["fill_in_sweep"] = bool(kt["zero"] < 0 and kt["check"] >= 0 and wl.fsa.all_compact())
     if kt["zero"] < 0 and kt["check"] >= 0:
         old = os.environ.get("WF_FILL_SIDE_STREAM")
         os.environ["WF_FILL_SIDE_STREAM"] = "1"
@@ -568,15 +569,23 @@ def main():
     }
     if rank == 0:
         kt = kernel_times(wl, stream)
+        fill_in_sweep = kt.pop("fill_in_sweep")
         kb = wl.kernel_bytes(lin=kt["check"] >= 0)
         dom = max(kt, key=lambda k: kt[k])
+        if fill_in_sweep:
+            # the gradient zero-fill is done by extra workgroups of the sweep's own launch: that launch's algorithmic
+            # bytes are the sweep's plus the fill's (kernels.zero is the fill measured alone, on the side stream)
+            kb = dict(kb, sweep=kb["sweep"] + kb["zero"], sweep_alone=kb["sweep"])
         ach = kb[dom] / (kt[dom] * 1e-3) / 1e9
         default_wl = (args.workload == "cfg3_ctc_bpe5k_num" and args.batch == 32 and args.frames == 500
                       and not args.ragged)
         if default_wl:
             kname = KERNEL_NAMES.get(dom, dom)
         elif wl.S_mean > 4096 and kt["check"] >= 0:      # large denominators (cfg4): DESIGN.md section 4
-            kname = {"sweep": "sweep_linbig_kernel", "post": "post_big_kernel"}.get(dom, KERNEL_NAMES.get(dom, dom))
+            from waterfall_amd import csrc_layout as _cl
+            hubform = bool(wl.gh[_cl.HDR_WORDS + _cl.INFO["HUB_G"]] > 0)
+            kname = ({"sweep": "sweep_hub_kernel", "post": "post_hub_kernel"} if hubform else
+                     {"sweep": "sweep_linbig_kernel", "post": "post_big_kernel"}).get(dom, KERNEL_NAMES.get(dom, dom))
         else:
             kname = dom + " (kernel picked by graph size: DESIGN.md section 4)"
         rp_us = rocprof_avg_us(dom, default_wl)
@@ -592,15 +601,21 @@ def main():
                            "frac_rocprof": kb[dom] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS if rp_us else None,
                            "profiles_match_kernel_source": profiles_current(),
                            "kernel_source_sha256": kernel_source_hash(),
-                           "note": "dominant kernel by duration. The alpha/beta sweep is dependency-latency bound (T "
-                                   "sequential frame steps; kernels.sweep.us_per_frame_step is its figure of merit); the "
-                                   "only bandwidth-bound kernel is the gradient zero-fill, which runs beside the sweep on "
-                                   "a side stream (kernels.zero). avg_launch_ms is the HIP-event interval around the launch on its "
-                                   "stream (it includes the launch / event latency and, for the sweep, the fork of the fill: "
-                                   "~7 us more than the kernel's own duration in the committed rocprofv3 summary, "
-                                   "rocprof_avg_launch_us). traffic: profiles/" + PROFILE_TAG + "_pmc_traffic.json"}
+                           "fill_in_sweep_launch": fill_in_sweep,
+                           "note": "dominant kernel by duration. The alpha/beta recursion itself is dependency-latency bound (T "
+                                   "sequential frame steps on 2B chain wavefronts; kernels.sweep.us_per_frame_step is its figure "
+                                   "of merit, kernels.sweep_alone its bytes); with fill_in_sweep_launch the same launch also "
+                                   "carries the bandwidth-bound half of the step -- the zero-fill of the gradient box by extra "
+                                   "workgroups on the CUs the 2B sweep workgroups leave idle -- and its algorithmic bytes are the "
+                                   "sum of both (rows + emissions + the 4V-per-frame gradient rows of SURVEY.md 8(d)). "
+                                   "avg_launch_ms is the HIP-event interval around the launch on its stream (launch / event "
+                                   "latency included: a few us more than the kernel's own duration in the committed rocprofv3 "
+                                   "summary, rocprof_avg_launch_us). traffic: profiles/" + PROFILE_TAG + "_pmc_traffic.json "
+                                   "(FETCH_SIZE doubled + WRITE_SIZE, per launch)"}
         out["kernels"] = {k: {"avg_ms": kt[k], "algorithmic_bytes": kb[k],
                               "GBps": kb[k] / (kt[k] * 1e-3) / 1e9 if kt[k] > 0 else None} for k in kt}
+        if fill_in_sweep:
+            out["kernels"]["sweep"]["algorithmic_bytes_sweep_alone"] = kb["sweep_alone"]
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
         out["path_GBps_survey_8d"] = kb["path_survey_8d"] / (ms_step * 1e-3) / 1e9
         if world == 1:
