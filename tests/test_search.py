@@ -171,3 +171,21 @@ def test_get_lattice_call_shapes_of_lattice_analysis():
     assert torch.all(exact.get_tot_scores(True, False) >= tot_best - 1e-3)          # (fp64 exact vs fp32 search rounding)
     fp64 = decode.one_best_decoding(exact, use_double_scores=True)                # forwarded (VERDICT weak 16)
     assert fp64.scores.shape == (2,)
+
+
+def test_hub_with_hundreds_of_outgoing_arcs_and_log_total():
+    """A topology over 300 phones used as the decoding graph: the hub's ~600 outgoing arcs are dealt over the lanes
+    (arc-parallel expansion), every frame touches every state."""
+    c = util.random_case(60, "mmictc", B=3, T=40, L=4, P=300, den=True)
+    dense = wf.DenseFsaVec(torch.from_numpy(c["lp"]).to(DEV), torch.from_numpy(c["segs"]))
+    exact = wf.best_path(c["fsa"], dense)
+    out = wf.pruned_search(c["fsa"], dense, INF, 0, 0, use_double_scores=True)
+    assert torch.equal(out["scores"], exact["scores"]) and torch.equal(out["arcs"], exact["arcs"])
+    tot = wf.tot_scores(c["fsa"], dense, True, True).cpu().numpy()
+    np.testing.assert_allclose(out["tot_log"].cpu().numpy(), tot, rtol=1e-6, atol=1e-5)
+    pr = wf.pruned_search(c["fsa"], dense, 5.0, 0, 0, use_double_scores=True, return_active=True)
+    for i, g in enumerate(c["ographs"]):
+        T = int(c["segs"][i, 2])
+        s, path, tl, na = o.beam_search(g, c["lp"][i], T, 5.0)
+        assert pr["scores"][i].item() == s and list(pr["n_active"][i, :T + 1].cpu().numpy()) == na
+        np.testing.assert_allclose(pr["tot_log"][i].item(), tl, rtol=1e-6)

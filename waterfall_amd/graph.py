@@ -246,12 +246,15 @@ class GraphLoss(nn.Module):
                           target_lengths)
 
 
+_EAGER_DIRECT = True   # denominators (direct label columns) take the fused call too: no separate row-check pass
+
+
 def _graphloss(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double_scores, target_lengths):
     """graph.py:61-76: loss = -tot_scores (float32), reduced 'none' | 'sum' | 'mean' (/ target_lengths, then batch mean)."""
     beam = _beam_value(output_beam)
     lp = dense_fsa_vec.log_probs
     if (_EAGER and beam == 0.0 and not use_double_scores and lp.requires_grad and torch.is_grad_enabled()
-            and isinstance(decoding_graph, Fsa) and decoding_graph.all_compact()):
+            and isinstance(decoding_graph, Fsa) and (decoding_graph.all_compact() or _EAGER_DIRECT)):
         weights = None
         if reduction == 'mean':
             B = dense_fsa_vec.supervision_segments.shape[0]
