@@ -330,6 +330,7 @@ def test_full_size_mmictc_denominator_properties(oracle_lib):
 # the other kernels and the check -> fallback path, so that each one is held to the same tolerances.
 
 SWEEP_PATHS = {
+    "table_by_copy": {"WF_NO_TAB_KERNARG": "1"},          # per-call tables through the pinned ring instead of kernel arguments
     "default": {},                                                        # banded sweep, row check inside post_small_kernel
     "check_kernel": {"WF_NO_POST_CHECK": "1"},                             # separate row-check kernel before the posterior kernel
     "fill_side_stream": {"WF_FILL_SIDE_STREAM": "1"},                      # gradient zero-fill on the side stream instead of inside the sweep's launch

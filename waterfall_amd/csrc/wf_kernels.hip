@@ -2774,16 +2774,41 @@ __global__ void __launch_bounds__(64) gather_lin_kernel(GatherLinArgs p) {
 // log-prob) on 16 000 waves that need two residency rounds; this is one round with the chains overlapped.
 constexpr int kGFR = 4;
 
-__global__ void __launch_bounds__(64) gather_lin_small_kernel(GatherLinArgs p) {
+// TAB: the per-call utterance table arrives in the kernel arguments (int32 words, B <= kTabMaxB) instead of through a
+// host-to-device copy in front of this kernel (3.7 us + a launch gap on the critical path of a 100 us step): every
+// workgroup reads its entry from the argument segment, and the workgroups of frame block 0 write the table (and the
+// sequence -> utterance map) into the workspace, where the kernels that follow find it as usual.
+constexpr int kTabMaxB = 40;
+struct UttTab32 { int32_t w[kTabMaxB * WF_U_WORDS]; };
+struct GatherLinTabArgs {
+    GatherLinArgs g;
+    int64_t* utt_out;
+    int32_t* seq2utt_out;
+    UttTab32 tab;
+};
+static_assert(sizeof(GatherLinTabArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+template <bool TAB, typename Args>
+__device__ __forceinline__ void gather_lin_small_body(const Args& a) {
+    const GatherLinArgs& p = [&]() -> const GatherLinArgs& { if constexpr (TAB) return a.g; else return a; }();
     const int lane = threadIdx.x;
     const int t0 = blockIdx.x * kGFR, u = blockIdx.y;
-    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    auto U = [&](int i) -> int64_t {
+        if constexpr (TAB) return (int64_t)a.tab.w[u * WF_U_WORDS + i];
+        else return p.utt[(int64_t)u * WF_U_WORDS + i];
+    };
+    if constexpr (TAB) {
+        if (t0 == 0) {
+            if (lane < WF_U_WORDS) a.utt_out[(int64_t)u * WF_U_WORDS + lane] = (int64_t)a.tab.w[u * WF_U_WORDS + lane];
+            if (lane == 0 && a.seq2utt_out) a.seq2utt_out[U(WF_U_SEQ)] = u;
+        }
+    }
     if (t0 == 0 && lane == 0) p.flag[u] = 0;
-    const int T = (int)U[WF_U_T];
+    const int T = (int)U(WF_U_T);
     if (t0 >= T) return;
-    const int K = (int)U[WF_U_K], direct = (int)U[WF_U_DIRECT];
-    const int32_t* labels = p.blob + U[WF_U_LABELS];
-    const float* row0 = p.lp + U[WF_U_SEQ] * p.strideB + (U[WF_U_START] + t0) * p.strideT;
+    const int K = (int)U(WF_U_K), direct = (int)U(WF_U_DIRECT);
+    const int32_t* labels = p.blob + U(WF_U_LABELS);
+    const float* row0 = p.lp + U(WF_U_SEQ) * p.strideB + (U(WF_U_START) + t0) * p.strideT;
     const int k0 = lane, k1 = lane + 64;
     const int c0 = k0 < K ? (direct ? k0 : labels[k0]) : 0;
     const int c1 = k1 < K ? (direct ? k1 : labels[k1]) : 0;
@@ -2794,21 +2819,24 @@ __global__ void __launch_bounds__(64) gather_lin_small_kernel(GatherLinArgs p) {
         v0[r] = row[c0];
         v1[r] = row[c1];
     }
-    const int64_t pp = U[WF_U_PP];
-    double* prow = p.P + U[WF_U_P] + (int64_t)t0 * pp;
-    float* erow = p.E + U[WF_U_E] + (int64_t)t0 * K;
-    double* crow = p.cmax + U[WF_U_ROW0] + t0;
+    const int64_t pp = U(WF_U_PP);
+    double* prow = p.P + U(WF_U_P) + (int64_t)t0 * pp;
+    float* erow = p.E + U(WF_U_E) + (int64_t)t0 * K;
+    double* crow = p.cmax + U(WF_U_ROW0) + t0;
 #pragma unroll
     for (int r = 0; r < kGFR; ++r) {
         if (t0 + r >= T) break;
-        const float a = k0 < K ? v0[r] : -INFINITY, b = k1 < K ? v1[r] : -INFINITY;
-        float m = wave_max(fmaxf(a, b));
+        const float x = k0 < K ? v0[r] : -INFINITY, y = k1 < K ? v1[r] : -INFINITY;
+        float m = wave_max(fmaxf(x, y));
         if (!(m > -INFINITY)) m = 0.f;   // every label impossible in this frame: P = 0
-        if (k0 < K) { prow[r * pp + k0] = exp((double)a - (double)m); if (!direct) erow[r * K + k0] = a; }
-        if (k1 < K) { prow[r * pp + k1] = exp((double)b - (double)m); if (!direct) erow[r * K + k1] = b; }
+        if (k0 < K) { prow[r * pp + k0] = exp((double)x - (double)m); if (!direct) erow[r * K + k0] = x; }
+        if (k1 < K) { prow[r * pp + k1] = exp((double)y - (double)m); if (!direct) erow[r * K + k1] = y; }
         if (lane == 0) crow[r] = (double)m;
     }
 }
+
+__global__ void __launch_bounds__(64) gather_lin_small_kernel(GatherLinArgs p) { gather_lin_small_body<false>(p); }
+__global__ void __launch_bounds__(64) gather_lin_small_tab_kernel(GatherLinTabArgs p) { gather_lin_small_body<true>(p); }
 
 // ------------------------------------------------------------------------------------------
 // posterior / gradient rows
@@ -4066,7 +4094,7 @@ constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where not
 struct Hooks {
     int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
         zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache,
-        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern;
+        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern, no_tab_kernarg;
 };
 Hooks g_hooks;
 bool g_hooks_loaded = false;
@@ -4089,6 +4117,7 @@ void load_hooks() {
     h.quad_r = env_int("WF_QUAD_R", 0);
     h.no_post_check = env_int("WF_NO_POST_CHECK", 0); h.fill_side_stream = env_int("WF_FILL_SIDE_STREAM", 0);
     h.no_hub = env_int("WF_NO_HUB_SWEEP", 0); h.no_hub_pattern = env_int("WF_NO_HUB_PATTERN", 0);
+    h.no_tab_kernarg = env_int("WF_NO_TAB_KERNARG", 0);
     g_hooks = h;
     g_hooks_loaded = true;
 }
@@ -4798,14 +4827,28 @@ int build_seq2utt(const int32_t* seg, int B, int num_seqs, std::vector<int32_t>*
     return WF_OK;
 }
 
+// The per-call tables can ride in the arguments of gather_lin_small_tab_kernel (see there) when that kernel opens the
+// call, the batch is small, every table word fits 32 bits and every sequence of log_probs is named by a segment.
+bool tab_in_kernarg(const Plan& P, int num_seqs, bool want_seq2utt) {
+    if (hk().no_tab_kernarg || !P.lin || P.hub || P.linbig || P.kmax > 128 || hk().no_gather_small) return false;
+    if (P.B > kTabMaxB || (want_seq2utt && num_seqs != P.B)) return false;
+    for (int64_t v : P.utt) if (v < 0 || v > 0x7fffffff) return false;
+    return true;
+}
+
 int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
-                  int64_t strideB, int64_t strideT, hipStream_t st) {
+                  int64_t strideB, int64_t strideT, hipStream_t st, bool tab = false, bool tab_seq2utt = false) {
     if (P.hub) return WF_OK;   // sweep_hub_kernel reads log_probs itself (and clears the fallback flags)
     if (P.lin) {
         GatherLinArgs g{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), lp, strideB, strideT,
                         (float*)(ws + P.off_E), (double*)(ws + P.off_P), (double*)(ws + P.off_cmax),
                         (int32_t*)(ws + P.off_flag), P.linbig ? (float*)(ws + P.off_P) : nullptr};
-        if (!P.linbig && P.kmax <= 128 && !hk().no_gather_small)
+        if (tab) {
+            GatherLinTabArgs a;
+            a.g = g; a.utt_out = (int64_t*)(ws + P.off_utt); a.seq2utt_out = tab_seq2utt ? (int32_t*)(ws + P.off_seq2utt) : nullptr;
+            for (size_t i = 0; i < P.utt.size(); ++i) a.tab.w[i] = (int32_t)P.utt[i];
+            hipLaunchKernelGGL(gather_lin_small_tab_kernel, dim3((std::max(P.Tlong, 1) + kGFR - 1) / kGFR, P.B), dim3(64), 0, st, a);
+        } else if (!P.linbig && P.kmax <= 128 && !hk().no_gather_small)
             hipLaunchKernelGGL(gather_lin_small_kernel, dim3((std::max(P.Tlong, 1) + kGFR - 1) / kGFR, P.B), dim3(64), 0, st, g);
         else
             hipLaunchKernelGGL(gather_lin_kernel, dim3(std::max(P.Tlong, 1), P.B), dim3(64), 0, st, g);
@@ -4980,8 +5023,11 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
     std::vector<int32_t> seq2utt;
     if (need_ab || pruned) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
-    rc = upload_tables(P, ws, (need_ab || pruned) ? seq2utt.data() : nullptr, num_seqs, st, !use_scratch);
-    if (rc) return rc;
+    const bool tab = tab_in_kernarg(P, num_seqs, need_ab || pruned) && !pruned;
+    if (!tab) {
+        rc = upload_tables(P, ws, (need_ab || pruned) ? seq2utt.data() : nullptr, num_seqs, st, !use_scratch);
+        if (rc) return rc;
+    }
     g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = g_tm.have_check = false;
     // Fork: zero-fill the gradient box on the side stream while the sweeps (which occupy only 2B
     // workgroups) run; post_kernel then only scatters the K posteriors per row.
@@ -4991,7 +5037,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
                            (P.hub || ((overlap || !P.any_compact) && post_small_fits(P)));
     ForkGuard guard(st);   // every return below first makes `st` wait for the side stream
     if ((rc = tm_record(0, st))) return rc;
-    rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st);
+    rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st, tab, need_ab || pruned);
     if (rc) return rc;
     if ((rc = tm_record(1, st))) return rc;
     // The fill rides in the banded sweep's own launch (extra workgroups) when the box is one flat, 16-byte aligned run and
