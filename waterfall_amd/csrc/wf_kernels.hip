@@ -3931,8 +3931,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
             const float lo = max(cutoff, ord2f(s_min));
             inv_width = fmax > lo ? (float)kSearchBins / (fmax - lo) : 0.f;
             s_hist[tid] = 0;
+            __syncthreads();   // (every lane has read s_nsurv by now; cpk / cls of the first run are visible)
             if (tid == 0) { s_nsurv = 0; s_keepbin = tighten ? 0 : kSearchBins - 1; }
-            __syncthreads();
             for (int i0 = 0; i0 < n; i0 += kSearchUnroll * kSearchThreads) {
                 unsigned long long pk[kSearchUnroll];
 #pragma unroll
