@@ -47,7 +47,7 @@ inline size_t fsa_words_bound(size_t S, size_t A) {
     const size_t K = 2 * A + 1;
     size_t w = 0;
     w += pad4(S + 1) + 4 * pad4(A);          // in_off, in_src, in_col, in_w, in_arc
-    w += pad4(S + 1) + 4 * pad4(A);          // out_off, out_dst, out_col, out_w, out_arc
+    w += pad4(S + 1) + 4 * pad4(A) + pad4(4 * A);   // out_off, out_dst, out_col, out_w, out_arc, out_rec
     w += pad4(K + 1) + 4 * pad4(A);          // lab_off, lab_src, lab_dst, lab_w, lab_col
     w += pad4(K);                            // labels
     w += 3 * pad4(A);                        // fin_src, fin_w, fin_arc (NF <= A)
@@ -123,7 +123,7 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
     I[WF_I_S] = S; I[WF_I_A] = A; I[WF_I_NF] = NF; I[WF_I_K] = K; I[WF_I_DIRECT] = direct;
     I[WF_I_ARC_BASE] = a0;
     I[WF_I_MAX_LABEL] = max_label;
-    const size_t need = 2 * pad4(S + 1) + 12 * pad4(A) + pad4(K + 1) + pad4(K) + 3 * pad4(NF) + 4 * pad4(S) + pad4(A + NF);
+    const size_t need = 2 * pad4(S + 1) + 12 * pad4(A) + pad4(4 * (size_t)A) + pad4(K + 1) + pad4(K) + 3 * pad4(NF) + 4 * pad4(S) + pad4(A + NF);
     if (cur + need > limit) return wf_fail(WF_ENOSPC, "wf_graph_prepare: blob too small at fsa %d", g);
     X.cnt.assign(std::max(S, K) + 1, 0);
     X.pos.resize(std::max(S, K) + 1);
@@ -161,8 +161,9 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
     }
     // ---- outgoing CSR: emitting arcs in original order grouped by src (stable)
     {
-        int o_off = take(S + 1), o_dst = take(A), o_col = take(A), o_w = take(A), o_arc = take(A);
+        int o_off = take(S + 1), o_dst = take(A), o_col = take(A), o_w = take(A), o_arc = take(A), o_rec = take(4 * (size_t)A);
         I[WF_I_OUT_OFF] = o_off; I[WF_I_OUT_DST] = o_dst; I[WF_I_OUT_COL] = o_col; I[WF_I_OUT_W] = o_w; I[WF_I_OUT_ARC] = o_arc;
+        I[WF_I_OUT_REC] = o_rec;
         int32_t* cnt = X.cnt.data();
         std::fill(cnt, cnt + S + 1, 0);
         for (int a : X.em) cnt[arcs[4 * (size_t)a] + 1]++;
@@ -177,6 +178,8 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
             B[o_col + q] = X.col[j];
             B[o_w + q] = r[3];
             B[o_arc + q] = X.em[j];
+            int32_t* rec = B + o_rec + 4 * (size_t)q;
+            rec[0] = r[1]; rec[1] = X.col[j]; rec[2] = r[3]; rec[3] = X.em[j];
         }
         int o_h = take(S), nh = 0, maxout = 0, nover = 0, over = 0;
         for (int s2 = 0; s2 < S; ++s2) {

@@ -85,6 +85,8 @@ enum {
     WF_I_HUB_XCOL = 53,    // [NX] their columns
     WF_I_HUB_FINW = 54,    // float bits: weight of the hub's final arc
     WF_I_OUT_ARC = 55,     // [A] original arc index (local to the FSA) of every entry of the outgoing CSR
+    WF_I_OUT_REC = 56,     // [A][4] {dst, column, weight bits, arc index} of every entry of the outgoing CSR in one 16-byte
+                           // record (search_kernel: one random access per arc instead of four)
 };
 #define WF_HUB_MAX_G 3
 #define WF_HUB_MAX_NC 4

@@ -3634,7 +3634,7 @@ constexpr int kSearchThreads = 1024;
 constexpr int kSearchXL = 2048;   // survivors whose arcs / scores / degree prefix are in the LDS at a time
 constexpr int kSearchCL = 6144;   // candidates of a frame kept in the LDS (the rest in the workspace)
 constexpr int kSearchBins = 1024;
-constexpr int kSearchUnroll = 4;
+constexpr int kSearchUnroll = 1;
 enum { WF_SR_SOFF = 0, WF_SR_XOFF = 1, WF_SR_CAP = 2, WF_SR_AOFF = 3, WF_SR_ARCOFF = 4, WF_SR_WORDS = 6 };
 
 struct SearchArgs {
@@ -3700,7 +3700,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
     const int32_t* dst = p.blob + I[WF_I_OUT_DST];
     const int32_t* col = p.blob + I[WF_I_OUT_COL];
     const float* w = (const float*)(p.blob + I[WF_I_OUT_W]);
-    const int32_t* oarc = p.blob + I[WF_I_OUT_ARC];
+    const int4* orec = (const int4*)(p.blob + I[WF_I_OUT_REC]);
     const int32_t* labels = p.blob + I[WF_I_LABELS];
     const int64_t soff = R[WF_SR_SOFF];
     const int cap = (int)R[WF_SR_CAP];
@@ -3792,10 +3792,10 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
                 float we[kSearchUnroll];
 #pragma unroll
                 for (int j = 0; j < kSearchUnroll; ++j) {
-                    const int c = col[q[j]];
-                    d[j] = dst[q[j]];
-                    ar[j] = oarc[q[j]];
-                    we[j] = w[q[j]] + erow[direct ? c : labels[c]];
+                    const int4 rec = orec[q[j]];   // {dst, column, weight, arc id}: one 16-byte access per arc
+                    d[j] = rec.x;
+                    ar[j] = rec.w;
+                    we[j] = __int_as_float(rec.z) + erow[direct ? rec.y : labels[rec.y]];
                 }
                 if (!log_pass) {
                     // one 64-bit atomic max per arc: the tropical value of the destination, ties to the lowest arc index
@@ -5603,7 +5603,7 @@ int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* s
         if (g < 0 || g >= G) return wf_fail(WF_ERANGE, "utt2fsa[%d] = %d out of range", i, g);
         const int32_t* I = H + WF_HDR_WORDS + (size_t)g * WF_INFO_WORDS;
         if (I[WF_I_MAX_LABEL] >= V) return wf_fail(WF_ERANGE, "fsa %d uses label %d but log_probs has V=%d columns", g, I[WF_I_MAX_LABEL], V);
-        if (I[WF_I_A] > 0 && !I[WF_I_OUT_ARC]) return wf_fail(WF_EUNSUPPORTED, "prepared graph has no outgoing-arc index (prepared by an older library)");
+        if (I[WF_I_A] > 0 && !I[WF_I_OUT_REC]) return wf_fail(WF_EUNSUPPORTED, "prepared graph has no outgoing-arc index (prepared by an older library)");
         const int b = seg[3 * i], st = seg[3 * i + 1], T = seg[3 * i + 2];
         if (b < 0 || st < 0 || T < 0) return wf_fail(WF_ERANGE, "segment %d = (%d,%d,%d) out of range", i, b, st, T);
         int64_t* U = &S->P.utt[(size_t)i * WF_U_WORDS];
