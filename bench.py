@@ -654,6 +654,7 @@ def main():
                     n2 = max(5, args.steps // 5)
                     d2 = float(np.median(time_steps(w2, n2, 3, None, stream, fused[:3], min_region_s=0.03)))
                     k2 = kernel_times(w2, stream, reps=5)
+                    k2["fill_in_sweep"] = bool(k2["fill_in_sweep"])
                     others[name] = {"frames_per_s": w2.frames / (d2 / n2), "ms_per_step": d2 / n2 * 1e3,
                                     "arc_updates_per_sec": 2 * w2.arc_updates / (d2 / n2), "kernels_ms": k2,
                                     "desc": WORKLOADS[name]["desc"]}
