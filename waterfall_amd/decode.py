@@ -91,10 +91,8 @@ def get_lattice(log_prob, log_prob_len, decoding_graph, search_beam=20, output_b
                 max_active_states=10000, subsampling_factor=1):
     """k2.get_lattice (icefall-style signature; lattice_analysis.py:125).  log_prob: [B, T, V] on the GPU.
     The search itself runs at the first query (get_tot_scores / one_best_decoding)."""
-    beam = float(search_beam)
-    if output_beam is not None and 0 < float(output_beam) < beam:
-        pass   # (k2 prunes the finished lattice backwards with output_beam; the forward search keeps search_beam)
-    search = dict(search_beam=beam, min_active_states=int(min_active_states), max_active_states=int(max_active_states))
+    # (output_beam: k2 prunes the finished lattice backwards with it; the forward search here keeps search_beam alone)
+    search = dict(search_beam=float(search_beam), min_active_states=int(min_active_states), max_active_states=int(max_active_states))
     return DenseLattice(_as_vec(decoding_graph, log_prob.shape[0]), _dense_from(log_prob, log_prob_len), search)
 
 
