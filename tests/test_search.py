@@ -189,3 +189,16 @@ def test_hub_with_hundreds_of_outgoing_arcs_and_log_total():
         s, path, tl, na = o.beam_search(g, c["lp"][i], T, 5.0)
         assert pr["scores"][i].item() == s and list(pr["n_active"][i, :T + 1].cpu().numpy()) == na
         np.testing.assert_allclose(pr["tot_log"][i].item(), tl, rtol=1e-6)
+
+
+def test_random_graphs_with_exact_ties_against_oracle():
+    """tools/fuzz_search.py (40 seeded cases): random graphs with skewed out-degrees, states of thousands of arcs,
+    quantised weights and emissions (exact ties on the arg-max and on the beam boundary), random beams; also the
+    max_active_states properties.  Runs as a child process: the tool is a script."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "fuzz_search.py"), "40", "7", "8000"], cwd=root,
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
