@@ -1,5 +1,7 @@
 """Randomised parity run (GPU): random topology / sizes / ragged lengths / sweep path against the numpy oracle.
-usage: python tools/fuzz_gpu.py [cases] [seed] [big]   (test infrastructure: imports oracle/)"""
+usage: python tools/fuzz_gpu.py [cases] [seed] [big|hub]   (test infrastructure: imports oracle/)
+big: larger cases (more kernel instantiations); hub: denominators over 128..900 phones (sweep_hub_kernel / post_hub_kernel
+and their fallbacks).  A third of the cases run with a finite output_beam (pruned lattice) against the oracle's."""
 import os
 import sys
 
@@ -15,6 +17,8 @@ import waterfall_amd as wf  # noqa: E402
 PATHS = [{}, {"WF_NO_BAND_SWEEP": "1"}, {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "1"}, {"WF_FORCE_FALLBACK": "1"},
          {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "2"}, {"WF_BIG_MIN_S": "1"}, {"WF_BIG_MIN_S": "1", "WF_POST_BIG_MIN_S": "1"},
          {"WF_NO_GATHER_SMALL": "1"}]
+HUB_PATHS = [{}, {}, {"WF_NO_HUB_PATTERN": "1"}, {"WF_NO_HUB_SWEEP": "1"}, {"WF_FORCE_FALLBACK": "1"}, {"WF_NO_TAB_KERNARG": "1"}]
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 topos = sorted(wf.TOPOLOGIES)
@@ -22,9 +26,15 @@ bad = 0
 for case in range(n):
     topo = topos[rng.integers(len(topos))]
     den = bool(rng.integers(2))
-    big = len(sys.argv) > 3   # third argument: larger cases (more kernel instantiations)
+    big = mode == "big"
     B, T, L, P = int(rng.integers(1, 10)), int(rng.integers(1, 300 if big else 90)), int(rng.integers(0, 90 if big else 13)), int(rng.integers(2, 45 if big else 13))
     env = PATHS[rng.integers(len(PATHS))]
+    if mode == "hub":
+        den, B, T, P = True, int(rng.integers(1, 5)), int(rng.integers(1, 70)), int(rng.integers(128, 900))
+        while topo == "ctc":   # the full CTC topology has O(P^2) arcs
+            topo = topos[rng.integers(len(topos))]
+        env = HUB_PATHS[rng.integers(len(HUB_PATHS))]
+    beam = [None, None, 4.0, 9.0][rng.integers(4)]
     c = util.random_case(int(rng.integers(1 << 30)), topo, B=B, T=T, L=L, P=P, den=den, ragged=bool(rng.integers(2)))
     for k in list(os.environ):
         if k.startswith("WF_"):
@@ -44,10 +54,11 @@ for case in range(n):
         c["lp"], c["segs"] = lp2, segs2
     x = torch.from_numpy(c["lp"]).cuda().requires_grad_(True)
     dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
-    loss = wf.graphloss(c["fsa"], dense, reduction="none")
+    wf.set_output_beam_mode("pruned" if beam else "exact")
+    loss = wf.graphloss(c["fsa"], dense, output_beam=beam or 10, reduction="none")
     fin = torch.isfinite(loss)
     torch.where(fin, loss, torch.zeros_like(loss)).sum().backward()
-    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], beam, "none")
     got, g = loss.detach().cpu().numpy(), x.grad.cpu().numpy()
     ok = np.allclose(got, want, rtol=1e-4, atol=1e-4) and np.allclose(g, np.where(np.isfinite(wgrad), wgrad, 0), atol=1e-3) \
         and np.all(np.isfinite(g))
@@ -59,6 +70,9 @@ for case in range(n):
             ok = False
     if not ok:
         bad += 1
-        print("MISMATCH", case, topo, den, B, T, L, P, env, np.abs(got - want).max(), flush=True)
+        print("MISMATCH", case, topo, den, B, T, L, P, env, beam, np.abs(got - want).max(),
+              np.abs(g - np.where(np.isfinite(wgrad), wgrad, 0)).max(), flush=True)
+    elif case % 20 == 0:
+        print("ok", case, flush=True)
 print(f"{n} cases, {bad} mismatches", flush=True)
 sys.exit(1 if bad else 0)
