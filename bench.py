@@ -97,8 +97,12 @@ WORKLOADS = {
                                  desc="WSJ char 2state denominator (topology x B), V=59"),
     "cfg4_mmictc_bpe5k_den": dict(topo="mmictc", P=5000, L=64, den=True,
                                   desc="LS BPE-5k mmictc denominator, V=10001, S=10002, A=30002"),
+    "cfg4_mmictc_bpe5k_num": dict(topo="mmictc", P=5000, L=64, den=False,
+                                  desc="LS BPE-5k mmictc numerator, V=10001, L=64"),
     "cfg4_3state-skip_bpe5k_num": dict(topo="3state-skip", P=5000, L=64, den=False,
                                        desc="LS BPE-5k 3state-skip numerator, V=15001, L=64"),
+    "cfg4_3state-skip_bpe5k_den": dict(topo="3state-skip", P=5000, L=64, den=True,
+                                       desc="LS BPE-5k 3state-skip denominator, V=15001, S=10002, A=25002"),
 }
 
 

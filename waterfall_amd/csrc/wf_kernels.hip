@@ -1578,22 +1578,45 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
         const int lw = wave - kHubCompute / 64;
         const int nchunk = (K + 63) >> 6;
         const int nb = p.chunk;   // row buffers in the LDS (2 or 3)
+        // 16-byte pieces (gfx950: 64 lanes x 4 floats per wave-instruction) over the row's whole 256-float blocks, 4-byte
+        // pieces over the rest: a quarter of the DMA instructions, and a frame's batch stays far below the 63 requests that
+        // vmcnt can count, so that two batches can be in flight
+        const int n16 = (p.ablate & 32) ? 0 : K >> 8;
+        int nreq = 0;   // requests per frame of this wavefront
+        for (int c = lw; c < n16; c += kHubLoad / 64) ++nreq;
+        for (int c = 4 * n16 + lw; c < nchunk; c += kHubLoad / 64) ++nreq;
+        nreq = uni(nreq);
         auto issue = [&](const int frame) __attribute__((always_inline)) {
             const float* row = lpbase + (int64_t)(dir ? T - 1 - frame : frame) * p.strideT;
             float* dst = pbuf + (size_t)(frame % nb) * kp;
             if (p.ablate & 2) return;   // (timing aid: no loads)
-            for (int c = lw; c < nchunk; c += kHubLoad / 64)
+            for (int c = lw; c < n16; c += kHubLoad / 64)
+                __builtin_amdgcn_global_load_lds(row + 256 * c + 4 * lane, (__attribute__((address_space(3))) float*)(dst + 256 * c), 16, 0, 0);
+            for (int c = 4 * n16 + lw; c < nchunk; c += kHubLoad / 64)
                 __builtin_amdgcn_global_load_lds(row + min(64 * c + lane, K - 1), (__attribute__((address_space(3))) float*)(dst + 64 * c), 4, 0, 0);
+        };
+        // waits until at most the newest batch (nreq requests) is outstanding: loads complete in order, so every older
+        // batch has landed (s_waitcnt takes an immediate: one case per count; vmcnt's low four bits)
+        auto wait_older = [&]() __attribute__((always_inline)) {
+            switch ((p.ablate & 2) ? 0 : nreq) {
+#define WF_CASE(n) case n: __builtin_amdgcn_s_waitcnt(0x0f70 | n); break;
+                WF_CASE(1) WF_CASE(2) WF_CASE(3) WF_CASE(4) WF_CASE(5) WF_CASE(6) WF_CASE(7) WF_CASE(8)
+                WF_CASE(9) WF_CASE(10) WF_CASE(11) WF_CASE(12) WF_CASE(13) WF_CASE(14) WF_CASE(15)
+#undef WF_CASE
+                default: __builtin_amdgcn_s_waitcnt(0x0f70);   // (0, or more than the field holds: everything)
+            }
         };
         if (T > 0) issue(0);
         if (nb == 3) {
-            if (T > 1) issue(1);
-            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+            // three row buffers: frame s + 2 is requested at the START of step s (its buffer, frame s - 1's, is free since the
+            // last barrier), frame s + 1 -- requested a whole step earlier -- is awaited before the barrier that ends step s:
+            // a request has two frame steps to land
+            if (T > 1) { issue(1); wait_older(); } else __builtin_amdgcn_s_waitcnt(0x0f70);
             __builtin_amdgcn_s_barrier();         // the initial row is stored, frame 0 is staged
             for (int step = 0; step < T; ++step) {
-                __builtin_amdgcn_s_waitcnt(0x0f70);   // frame step + 1 has landed (requested one interval ago)
-                if (step + 2 < T) issue(step + 2);    // into the buffer of frame step - 1, free since the last barrier
-                __builtin_amdgcn_s_barrier();
+                if (step + 2 < T) { issue(step + 2); wait_older(); }
+                else __builtin_amdgcn_s_waitcnt(0x0f70);
+                if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
             }
         } else {
             __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -1601,7 +1624,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             for (int step = 0; step < T; ++step) {
                 if (step + 1 < T) issue(step + 1);
                 __builtin_amdgcn_s_waitcnt(0x0f70);
-                __builtin_amdgcn_s_barrier();
+                if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
             }
         }
         return;
@@ -1639,11 +1662,12 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
     const int xc = NX > 0 ? xcol[min(tid, NX - 1)] : 0;
 
     // ---- initial row: alpha_0 = delta(hub); beta_T = the hub's final weight
-    double a[kHubSlots][G];
+    // (the groups' values are fp32 registers: what the rows hold; the hub's value and its sum are fp64)
+    float a[kHubSlots][G];
 #pragma unroll
     for (int k = 0; k < kHubSlots; ++k)
 #pragma unroll
-        for (int i = 0; i < G; ++i) a[k][i] = 0.0;
+        for (int i = 0; i < G; ++i) a[k][i] = 0.f;
     double h = dir ? exp((double)finw) : 1.0;
     {
         float* row = arena + (int64_t)(dir ? T : 0) * S;
@@ -1676,7 +1700,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             const float* pc = pbuf + (size_t)ib * kp;
             ib = ib + 1 == nb ? 0 : ib + 1;
             const int f = TR ? T - 1 - step : step;
-            float* srow = arena + (int64_t)(TR ? f : f + 1) * S;
+            float* srow = arena + ((p.ablate & 1) ? (int64_t)0 : (int64_t)(TR ? f : f + 1) * S);   // (ablate: timing aid)
             cum += (double)sh;
             if (tid == 0) goff[step + 1] = cum;
             double part = 0.0;      // this lane's share of the hub's new value
@@ -1685,9 +1709,77 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             const int shc = min(max(sh, -16), 64);   // rides in the exp2 argument (fp32: no underflow for lp > -43, no overflow)
             const int shr = sh - shc;                // the rest, by ldexp (uniform, rare: the first frames)
             const float shf = (float)shc;
+            // Fast frame body (known pattern, the usual case shr == 0, the slot count NS a compile-time constant): ONE basic
+            // block for all slots -- every emission is requested from the LDS before the first is used, no uniform branch
+            // per slot (`k < nslot`, `shr`) and no exec mask but on the last slot's store (slots below it are full in
+            // every lane), so the scheduler overlaps the slots' LDS reads and exp2s.  All of a group's arithmetic is fp32
+            // (the state values are fp32 registers and leave as they are: no conversion on the way in or out -- the
+            // conversions were four of a slot's six quarter-rate instructions); a lane's share of the hub's sum goes to
+            // fp64 once per frame.  The row's exponent comes from the stored values' bit patterns (positive floats order
+            // like unsigned integers: one max per slot).
+            auto fast = [&](const auto nst) __attribute__((always_inline)) {
+                constexpr int NS = decltype(nst)::value;
+                constexpr HubPattern pat = kHubPatterns[PAT >= 0 ? PAT : 0];
+                float lv[NS][NC];
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) lv[k][c] = pc[poff[k][c]];
+                const float h32 = (float)h;
+                float part32 = 0.f, self32 = 0.f;
+                unsigned eb = 0;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    float pr[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) pr[c] = __builtin_amdgcn_exp2f(fmaf(lv[k][c], kLog2e, shf));
+                    float nv[G];
+#pragma unroll
+                    for (int i = 0; i < G; ++i) nv[i] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < pat.n; ++e) {
+                        const int ii = pat.e[e] >> 4, jj = (pat.e[e] >> 2) & 3, c = pat.e[e] & 3;
+                        const int i = TR ? jj : ii, j = TR ? ii : jj;
+                        if (i == G && j == G) self32 += pr[c < NC ? c : 0];
+                        else {
+                            const float vj = j == G ? h32 : a[k][j < G ? j : 0];
+                            if (i == G) part32 = fmaf(pr[c < NC ? c : 0], vj, part32);
+                            else nv[i < G ? i : 0] = fmaf(pr[c < NC ? c : 0], vj, nv[i < G ? i : 0]);
+                        }
+                    }
+                    HubRow<G> v;
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        a[k][i] = nv[i];
+                        v.v[i] = nv[i];
+                        eb = max(eb, __builtin_bit_cast(unsigned, nv[i]));
+                    }
+                    const int g = tid + k * kHubCompute;
+                    if (k < NS - 1 || g < NG) *(HubRow<G>*)(srow + 1 + g * G) = v;
+                }
+                part += (double)part32;
+                selfd += (double)self32;
+                const int e32 = (int)(eb >> 23);
+                emine = e32 > 0 ? e32 + (1023 - 127) : 0;
+            };
+            bool done = false;
+            if (PAT >= 0 && shr == 0 && !(p.ablate & 64)) {
+                done = true;
+                switch (nslot) {
+                    case 1: fast(std::integral_constant<int, 1>{}); break;
+                    case 2: fast(std::integral_constant<int, 2>{}); break;
+                    case 3: fast(std::integral_constant<int, 3>{}); break;
+                    case 4: fast(std::integral_constant<int, 4>{}); break;
+                    case 5: fast(std::integral_constant<int, 5>{}); break;
+                    case 6: fast(std::integral_constant<int, 6>{}); break;
+                    case 7: fast(std::integral_constant<int, 7>{}); break;
+                    default: done = false;
+                }
+            }
+            static_assert(kHubSlots == 7, "the switch above lists the slot counts");
 #pragma unroll
             for (int k = 0; k < kHubSlots; ++k) {
-                if (k < nslot) {
+                if (k < nslot && !done) {
                     // exp(lp) * 2^shf: the row's rescaling rides in the exponent argument
                     float pr[NC];
 #pragma unroll
@@ -1706,7 +1798,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
                             const int i = TR ? jj : ii, j = TR ? ii : jj;
                             if (i == G && j == G) selfd += prd[c < NC ? c : 0];
                             else {
-                                const double vj = j == G ? h : a[k][j < G ? j : 0];
+                                const double vj = j == G ? h : (double)a[k][j < G ? j : 0];
                                 if (i == G) part = fma(prd[c < NC ? c : 0], vj, part);
                                 else nv[i < G ? i : 0] = fma(prd[c < NC ? c : 0], vj, nv[i < G ? i : 0]);
                             }
@@ -1722,7 +1814,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
                                     for (int c = 1; c < NC; ++c) cp = fmaf(cf[i][j][c], pr[c], cp);
                                     if (i == G && j == G) selfd += (double)cp;
                                     else {
-                                        const double vj = j == G ? h : a[k][j < G ? j : 0];
+                                        const double vj = j == G ? h : (double)a[k][j < G ? j : 0];
                                         if (i == G) part = fma((double)cp, vj, part);
                                         else nv[i < G ? i : 0] = fma((double)cp, vj, nv[i < G ? i : 0]);
                                     }
@@ -1734,18 +1826,14 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
 #pragma unroll
                         for (int i = 0; i < G; ++i) nv[i] = ldexp(nv[i], shr);
                     }
+                    HubRow<G> v;
 #pragma unroll
                     for (int i = 0; i < G; ++i) {
-                        a[k][i] = nv[i];
+                        a[k][i] = v.v[i] = (float)nv[i];
                         emine = max(emine, f64_exp_field(nv[i]));
                     }
                     const int g = tid + k * kHubCompute;
-                    if (g < NG && !(p.ablate & 1)) {   // (ablate: timing aid)
-                        HubRow<G> v;
-#pragma unroll
-                        for (int i = 0; i < G; ++i) v.v[i] = (float)nv[i];
-                        *(HubRow<G>*)(srow + 1 + g * G) = v;
-                    }
+                    if (g < NG) *(HubRow<G>*)(srow + 1 + g * G) = v;
                 }
             }
             if (tid < NX) selfd += (double)__builtin_amdgcn_exp2f(fmaf(pc[xc], kLog2e, shf));
@@ -1755,7 +1843,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             emine = wave_max_i(emine);
             const int par = (step & 1) * 16;
             if (lane == 0) { red[par + wave] = part; rexp[par + wave] = emine; }
-            __syncthreads();
+            if (!(p.ablate & 4)) __syncthreads();   // (ablate: timing aid)
             static_assert(kHubCompute / 64 == 12, "the reduction below sums twelve partial values");
             double r[12];
             int ex[12];
