@@ -1069,6 +1069,23 @@ def test_hub_form_denominators(topo, path):
         assert np.all(grad[b, T:] == 0)
 
 
+@pytest.mark.parametrize("P", [900, 1700])
+@pytest.mark.parametrize("topo", HUB_TOPOS)
+def test_hub_split_ring(topo, P):
+    """sweep_hub_kernel's split ring (rows too long for three LDS buffers: cfg4's 3state-skip, V = 15001) forced at a
+    size the numpy oracle handles: 2 - 3 slots per lane, the last one partly filled and read from the back buffers."""
+    c = util.random_case(700 + len(topo), topo, B=3, T=33, L=4, P=P, den=True)
+    want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
+    run = lambda: fused_logsum(c["fsa"], c["lp"], c["segs"])
+    tot, grad = _with_env({"WF_HUB_FORCE_SPLIT": "1"}, run)
+    np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+    tot2, grad2 = _with_env({"WF_HUB_FORCE_SPLIT": "1", "WF_NO_HUB_SPLIT": "1"}, run)      # two whole-row buffers
+    assert np.array_equal(tot, tot2) and np.array_equal(grad, grad2)
+    tot3, grad3 = run()                                                                    # three whole-row buffers
+    assert np.array_equal(tot, tot3) and np.array_equal(grad, grad3)
+
+
 def test_label_grad_sums_kernel_matches_torch():
     """wf_label_grad_sums (the optional tail of the fused all-reduce buffer) on a strided gradient box."""
     from waterfall_amd.dist import fused_loss_stats

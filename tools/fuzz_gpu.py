@@ -1,6 +1,6 @@
 """Randomised parity run (GPU): random topology / sizes / ragged lengths / sweep path against the numpy oracle.
 usage: python tools/fuzz_gpu.py [cases] [seed] [big|hub]   (test infrastructure: imports oracle/)
-big: larger cases (more kernel instantiations); hub: denominators over 128..900 phones (sweep_hub_kernel / post_hub_kernel
+big: larger cases (more kernel instantiations); hub: denominators over 128..2400 phones (sweep_hub_kernel / post_hub_kernel
 and their fallbacks).  A third of the cases run with a finite output_beam (pruned lattice) against the oracle's."""
 import os
 import sys
@@ -17,7 +17,7 @@ import waterfall_amd as wf  # noqa: E402
 PATHS = [{}, {"WF_NO_BAND_SWEEP": "1"}, {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "1"}, {"WF_FORCE_FALLBACK": "1"},
          {"WF_NO_BAND_SWEEP": "1", "WF_NO_LIN_SWEEP": "2"}, {"WF_BIG_MIN_S": "1"}, {"WF_BIG_MIN_S": "1", "WF_POST_BIG_MIN_S": "1"},
          {"WF_NO_GATHER_SMALL": "1"}]
-HUB_PATHS = [{}, {}, {"WF_NO_HUB_PATTERN": "1"}, {"WF_NO_HUB_SWEEP": "1"}, {"WF_FORCE_FALLBACK": "1"}, {"WF_NO_TAB_KERNARG": "1"}]
+HUB_PATHS = [{}, {"WF_HUB_FORCE_SPLIT": "1"}, {"WF_HUB_FORCE_SPLIT": "1", "WF_NO_HUB_PATTERN": "1"}, {"WF_NO_HUB_PATTERN": "1"}, {"WF_NO_HUB_SWEEP": "1"}, {"WF_FORCE_FALLBACK": "1"}, {"WF_NO_TAB_KERNARG": "1"}]
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -30,7 +30,7 @@ for case in range(n):
     B, T, L, P = int(rng.integers(1, 10)), int(rng.integers(1, 300 if big else 90)), int(rng.integers(0, 90 if big else 13)), int(rng.integers(2, 45 if big else 13))
     env = PATHS[rng.integers(len(PATHS))]
     if mode == "hub":
-        den, B, T, P = True, int(rng.integers(1, 5)), int(rng.integers(1, 70)), int(rng.integers(128, 900))
+        den, B, T, P = True, int(rng.integers(1, 5)), int(rng.integers(1, 70)), int(rng.integers(128, 2400))
         while topo == "ctc":   # the full CTC topology has O(P^2) arcs
             topo = topos[rng.integers(len(topos))]
         env = HUB_PATHS[rng.integers(len(HUB_PATHS))]

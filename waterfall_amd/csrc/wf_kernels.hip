@@ -134,6 +134,9 @@ struct SweepArgs {
     float* ztail;
     int zntail;
     int nsweep;
+    // sweep_hub_kernel, split ring (rows too long for three whole LDS buffers): pitch of the three buffers of a row's
+    // front part and of the two buffers of its back part, in floats; 0: `chunk` whole-row buffers of pitch kpad
+    int hub_kpf, hub_kpb;
     int ablate;    // measurement aids, never set by the product path: bit 8 (WF_SWEEP_PROFILE=1) workgroup 0 prints its cycles per
                    // frame step; sweep_kernel, WF_SWEEP_ABLATE: 16 no register copy of streamed arcs, 32 no row stores, 64 no heavy
                    // states, 128 no light states (32-128 give wrong results: timing only)
@@ -1517,6 +1520,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_linbig_kernel(SweepArgs p) 
 constexpr int kHubCompute = 768;   // lanes that own groups (12 wavefronts); the other 4 wavefronts of the workgroup load
 constexpr int kHubSlots = 7;       // groups per compute lane: NG <= 7 * 768
 constexpr int kHubLoad = kMaxThreads - kHubCompute;
+constexpr size_t kHubLdsFixed = 32 * 8 + 32 * 4;   // LDS in front of the row buffers: partial sums and exponents of the hub
 
 // The arc patterns of the reference's two-state-per-phone topologies (utils/get_token_fst_*_k2.py) in hub form, as compile-
 // time entry lists "new value of i += P[class c] * value of j" (forward direction; i, j: 0 = x, 1 = x + 1, 2 = the hub),
@@ -1536,6 +1540,20 @@ constexpr int kHubNumPatterns = 5;
 
 // the G values of one group as one store (rows are 4-byte aligned; the groups start at state 1)
 template <int G> struct __attribute__((packed, aligned(4))) HubRow { float v[G]; };
+
+// Split ring of sweep_hub_kernel: the slots below *ks read their emissions from the front part of a row (columns below
+// *kf, three LDS buffers of pitch kpf), the others from its back part (two buffers of pitch kpb).  Needs the tokens of a
+// group numbered consecutively (column of group g, class c: c0 + g * cs + c), so that a slot's columns are one run.
+// The largest split whose parts fit their buffers (64 spare floats each: DMA pieces are whole, the last word is the
+// pad); *ks = 0: none.  Host (sizing the buffers) and device (finding the split again) share this function.
+__host__ __device__ inline void hub_split(int kpf, int kpb, int K, int c0, int cs, int* ks, int* kf) {
+    *ks = 0; *kf = 0;
+    for (int k = kHubSlots - 1; k >= 1; --k) {
+        const long long f = (long long)c0 + (long long)kHubCompute * k * cs;
+        if (f >= K) continue;
+        if (((f + 63) / 64) * 64 + 64 <= kpf && ((K - f + 63) / 64) * 64 + 64 <= kpb) { *ks = k; *kf = (int)f; return; }
+    }
+}
 
 // PAT: index into kHubPatterns (G = 2), or -1: the pattern is only known at run time.
 template <int G, int NC, int PAT>
@@ -1576,29 +1594,32 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
         // registers); with three row buffers frame s + 2 is requested while frame s is being used, and its arrival is
         // awaited a whole frame step later.  Raw s_barrier: __syncthreads() would drain the DMAs in flight.
         const int lw = wave - kHubCompute / 64;
-        const int nchunk = (K + 63) >> 6;
-        const int nb = p.chunk;   // row buffers in the LDS (2 or 3)
-        // 16-byte pieces (gfx950: 64 lanes x 4 floats per wave-instruction) over the row's whole 256-float blocks, 4-byte
-        // pieces over the rest: a quarter of the DMA instructions, and a frame's batch stays far below the 63 requests that
-        // vmcnt can count, so that two batches can be in flight
-        const int n16 = (p.ablate & 32) ? 0 : K >> 8;
-        int nreq = 0;   // requests per frame of this wavefront
-        for (int c = lw; c < n16; c += kHubLoad / 64) ++nreq;
-        for (int c = 4 * n16 + lw; c < nchunk; c += kHubLoad / 64) ++nreq;
-        nreq = uni(nreq);
-        auto issue = [&](const int frame) __attribute__((always_inline)) {
-            const float* row = lpbase + (int64_t)(dir ? T - 1 - frame : frame) * p.strideT;
-            float* dst = pbuf + (size_t)(frame % nb) * kp;
-            if (p.ablate & 2) return;   // (timing aid: no loads)
-            for (int c = lw; c < n16; c += kHubLoad / 64)
-                __builtin_amdgcn_global_load_lds(row + 256 * c + 4 * lane, (__attribute__((address_space(3))) float*)(dst + 256 * c), 16, 0, 0);
-            for (int c = 4 * n16 + lw; c < nchunk; c += kHubLoad / 64)
-                __builtin_amdgcn_global_load_lds(row + min(64 * c + lane, K - 1), (__attribute__((address_space(3))) float*)(dst + 64 * c), 4, 0, 0);
+        const int nb = p.chunk;   // whole-row buffers in the LDS (2 or 3)
+        // A run of n floats (row columns lo .. lo + n - 1) into an LDS buffer: 16-byte pieces (gfx950: 64 lanes x 4 floats
+        // per wave-instruction) over its whole 256-float blocks, 4-byte pieces over the rest -- a quarter of the DMA
+        // instructions, and a frame's batch stays far below the 63 requests that vmcnt can count, so that two batches can
+        // be in flight.  nreq_of: requests per run of this wavefront.
+        const bool only4 = p.ablate & 32;   // (timing aid: 4-byte pieces only)
+        auto nreq_of = [&](const int n) {
+            const int n16 = only4 ? 0 : n >> 8, nchunk = (n + 63) >> 6;
+            int r = 0;
+            for (int c = lw; c < n16; c += kHubLoad / 64) ++r;
+            for (int c = 4 * n16 + lw; c < nchunk; c += kHubLoad / 64) ++r;
+            return uni(r);
         };
-        // waits until at most the newest batch (nreq requests) is outstanding: loads complete in order, so every older
-        // batch has landed (s_waitcnt takes an immediate: one case per count; vmcnt's low four bits)
-        auto wait_older = [&]() __attribute__((always_inline)) {
-            switch ((p.ablate & 2) ? 0 : nreq) {
+        auto issue_run = [&](const float* src, float* dst, const int n) __attribute__((always_inline)) {
+            if (p.ablate & 2) return;   // (timing aid: no loads)
+            const int n16 = only4 ? 0 : n >> 8, nchunk = (n + 63) >> 6;
+            for (int c = lw; c < n16; c += kHubLoad / 64)
+                __builtin_amdgcn_global_load_lds(src + 256 * c + 4 * lane, (__attribute__((address_space(3))) float*)(dst + 256 * c), 16, 0, 0);
+            for (int c = 4 * n16 + lw; c < nchunk; c += kHubLoad / 64)
+                __builtin_amdgcn_global_load_lds(src + min(64 * c + lane, n - 1), (__attribute__((address_space(3))) float*)(dst + 64 * c), 4, 0, 0);
+        };
+        auto rowp = [&](const int frame) { return lpbase + (int64_t)(dir ? T - 1 - frame : frame) * p.strideT; };
+        // waits until at most the newest n requests are outstanding: loads complete in order, so everything requested
+        // before them has landed (s_waitcnt takes an immediate: one case per count; vmcnt's low four bits)
+        auto wait_but = [&](const int n) __attribute__((always_inline)) {
+            switch ((p.ablate & 2) ? 0 : n) {
 #define WF_CASE(n) case n: __builtin_amdgcn_s_waitcnt(0x0f70 | n); break;
                 WF_CASE(1) WF_CASE(2) WF_CASE(3) WF_CASE(4) WF_CASE(5) WF_CASE(6) WF_CASE(7) WF_CASE(8)
                 WF_CASE(9) WF_CASE(10) WF_CASE(11) WF_CASE(12) WF_CASE(13) WF_CASE(14) WF_CASE(15)
@@ -1606,15 +1627,39 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
                 default: __builtin_amdgcn_s_waitcnt(0x0f70);   // (0, or more than the field holds: everything)
             }
         };
+        if (p.hub_kpf > 0) {
+            // split ring: the front part of frame s + 2 (three buffers) and the back part of frame s + 1 (two buffers) are
+            // requested at the start of step s; the barrier that ends step s waits for all but the former -- most of a
+            // row has two frame steps to land, and the batch that has one is small
+            int Kf, ksplit;
+            hub_split(p.hub_kpf, p.hub_kpb, K, uni(blob[uni(I[WF_I_HUB_C0])]), uni(I[WF_I_HUB_CS]), &ksplit, &Kf);
+            float* fbuf = pbuf;
+            float* bbuf = pbuf + 3 * (size_t)p.hub_kpf;
+            const int nf = nreq_of(Kf);
+            auto front = [&](const int fr) __attribute__((always_inline)) { issue_run(rowp(fr), fbuf + (size_t)(fr % 3) * p.hub_kpf, Kf); };
+            auto back = [&](const int fr) __attribute__((always_inline)) { issue_run(rowp(fr) + Kf, bbuf + (size_t)(fr & 1) * p.hub_kpb, K - Kf); };
+            if (T > 0) { front(0); back(0); }
+            if (T > 1) { front(1); wait_but(nf); } else __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();         // the initial row is stored, frame 0 is staged
+            for (int step = 0; step < T; ++step) {
+                if (step + 1 < T) back(step + 1);
+                if (step + 2 < T) { front(step + 2); wait_but(nf); }
+                else __builtin_amdgcn_s_waitcnt(0x0f70);
+                if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
+        const int nreq = nreq_of(K);
+        auto issue = [&](const int frame) __attribute__((always_inline)) { issue_run(rowp(frame), pbuf + (size_t)(frame % nb) * kp, K); };
         if (T > 0) issue(0);
         if (nb == 3) {
             // three row buffers: frame s + 2 is requested at the START of step s (its buffer, frame s - 1's, is free since the
             // last barrier), frame s + 1 -- requested a whole step earlier -- is awaited before the barrier that ends step s:
             // a request has two frame steps to land
-            if (T > 1) { issue(1); wait_older(); } else __builtin_amdgcn_s_waitcnt(0x0f70);
+            if (T > 1) { issue(1); wait_but(nreq); } else __builtin_amdgcn_s_waitcnt(0x0f70);
             __builtin_amdgcn_s_barrier();         // the initial row is stored, frame 0 is staged
             for (int step = 0; step < T; ++step) {
-                if (step + 2 < T) { issue(step + 2); wait_older(); }
+                if (step + 2 < T) { issue(step + 2); wait_but(nreq); }
                 else __builtin_amdgcn_s_waitcnt(0x0f70);
                 if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
             }
@@ -1681,15 +1726,23 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
     // LDS offsets of this lane's emissions inside a row buffer, per owned group and class; a lane without a group in its last
     // slot reads the buffer's pad word (-inf: probability 0), so that its values stay 0 with no masking in the frame loop
     const int nb = p.chunk;
+    // split ring (see the loader wavefronts): slots >= ksplit read columns >= Kf from the back buffers
+    int ksplit = kHubSlots, Kf = 0;
+    const int kpf = p.hub_kpf > 0 ? p.hub_kpf : kp, kpb = p.hub_kpb;
+    if (p.hub_kpf > 0) hub_split(p.hub_kpf, p.hub_kpb, K, c0[0], cs, &ksplit, &Kf);
+    const int nfb = p.hub_kpf > 0 ? 3 : nb;
+    const float* bbuf = pbuf + 3 * (size_t)kpf - Kf;   // (indexed by column)
     int poff[kHubSlots][NC];
 #pragma unroll
     for (int k = 0; k < kHubSlots; ++k)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int g = tid + k * kHubCompute;
-            poff[k][c] = g < NG ? c0[c] + g * cs : kp - 1;
+            poff[k][c] = g < NG ? c0[c] + g * cs : (k < ksplit ? kpf - 1 : Kf + kpb - 1);
         }
-    if (tid < nb) pbuf[(size_t)tid * kp + kp - 1] = -INFINITY;   // (the DMA pieces end before the pad word)
+    // (the DMA pieces end before a buffer's pad word)
+    if (tid < nfb) pbuf[(size_t)tid * kpf + kpf - 1] = -INFINITY;
+    if (p.hub_kpf > 0 && tid < 2) pbuf[3 * (size_t)kpf + (size_t)tid * kpb + kpb - 1] = -INFINITY;
     __syncthreads();   // frame 0 is staged
     double cum = 0.0;
     // the frame loop, once per direction at compile time (TR: the backward sweep uses the transposed pattern)
@@ -1697,8 +1750,9 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
         constexpr bool TR = decltype(tr)::value;
         int sh = 0, ib = 0;
         for (int step = 0; step < T; ++step) {
-            const float* pc = pbuf + (size_t)ib * kp;
-            ib = ib + 1 == nb ? 0 : ib + 1;
+            const float* pc = pbuf + (size_t)ib * kpf;
+            const float* pcb = bbuf + (size_t)(step & 1) * kpb;   // (read by no slot unless the ring is split)
+            ib = ib + 1 == nfb ? 0 : ib + 1;
             const int f = TR ? T - 1 - step : step;
             float* srow = arena + ((p.ablate & 1) ? (int64_t)0 : (int64_t)(TR ? f : f + 1) * S);   // (ablate: timing aid)
             cum += (double)sh;
@@ -1724,7 +1778,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k)
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) lv[k][c] = pc[poff[k][c]];
+                    for (int c = 0; c < NC; ++c) lv[k][c] = (k < ksplit ? pc : pcb)[poff[k][c]];
                 const float h32 = (float)h;
                 float part32 = 0.f, self32 = 0.f;
                 unsigned eb = 0;
@@ -1783,7 +1837,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
                     // exp(lp) * 2^shf: the row's rescaling rides in the exponent argument
                     float pr[NC];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) pr[c] = __builtin_amdgcn_exp2f(fmaf(pc[poff[k][c]], kLog2e, shf));
+                    for (int c = 0; c < NC; ++c) pr[c] = __builtin_amdgcn_exp2f(fmaf((k < ksplit ? pc : pcb)[poff[k][c]], kLog2e, shf));
                     double nv[G];
 #pragma unroll
                     for (int i = 0; i < G; ++i) nv[i] = 0.0;
@@ -1836,7 +1890,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
                     if (g < NG) *(HubRow<G>*)(srow + 1 + g * G) = v;
                 }
             }
-            if (tid < NX) selfd += (double)__builtin_amdgcn_exp2f(fmaf(pc[xc], kLog2e, shf));
+            if (tid < NX) selfd += (double)__builtin_amdgcn_exp2f(fmaf((xc < Kf || ksplit == kHubSlots ? pc : pcb)[xc], kLog2e, shf));
             part = fma(h, selfd, part);
             if (shr) { asm volatile(""); part = ldexp(part, shr); }
             part = wave_sum_d(part);
@@ -3316,17 +3370,18 @@ __global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
     const float sa = (float)exp2(kk - (double)k1 - (double)k1);   // in [1, 4): the fractional part
     const float ha = ldexpf(arow[0] * sa, k1), hb = ldexpf(brow[0], k1);
     float chk = 0.f;
-    for (int g = tid; g < NG; g += 256) {
+    // one group: posteriors of its NC labels from alpha_t / beta_{t+1} of its G states (and the hub's)
+    auto group = [&](const float* ag, const float* bg, const float* eg, float* out) __attribute__((always_inline)) {
         float av[W], bv[W];
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            av[i] = ldexpf(arow[1 + g * G + i] * sa, k1);
-            bv[i] = ldexpf(brow[1 + g * G + i], k1);
+            av[i] = ldexpf(ag[i] * sa, k1);
+            bv[i] = ldexpf(bg[i], k1);
         }
         av[G] = ha; bv[G] = hb;
-        float pr[NC], acc[NC];
+        float acc[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { pr[c] = __builtin_amdgcn_exp2f(erow[c0[c] + g * cs] * kLog2e); acc[c] = 0.f; }
+        for (int c = 0; c < NC; ++c) acc[c] = 0.f;
 #pragma unroll
         for (int i = 0; i < W; ++i)
 #pragma unroll
@@ -3338,9 +3393,49 @@ __global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
                 }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const float val = acc[c] * pr[c];
+            const float val = acc[c] * __builtin_amdgcn_exp2f(eg[c] * kLog2e);
             chk += val;
-            grow[c0[c] + g * cs] = gs * val;
+            out[c] = gs * val;
+        }
+    };
+    // the reference's topologies number a phone's NC tokens consecutively: then a group's log-probs and gradient entries
+    // are one NC-float run like its states' values, and a lane moves each with one load / store (rows are only 4-byte
+    // aligned: packed types), kPostHubUn groups per iteration with every load issued before the first use
+    bool inter = cs == NC;
+#pragma unroll
+    for (int c = 1; c < NC; ++c) inter = inter && c0[c] == c0[0] + c;
+    if (inter) {
+        constexpr int UN = 4;
+        for (int g0 = tid; g0 < NG; g0 += 256 * UN) {
+            HubRow<G> A[UN], Bv[UN];
+            HubRow<NC> E[UN];
+#pragma unroll
+            for (int r = 0; r < UN; ++r) {
+                const int g = min(g0 + r * 256, NG - 1);
+                A[r] = *(const HubRow<G>*)(arow + 1 + g * G);
+                Bv[r] = *(const HubRow<G>*)(brow + 1 + g * G);
+                E[r] = *(const HubRow<NC>*)(erow + c0[0] + g * NC);
+            }
+#pragma unroll
+            for (int r = 0; r < UN; ++r) {
+                const int g = g0 + r * 256;
+                if (g < NG) {
+                    HubRow<NC> O;
+                    group(A[r].v, Bv[r].v, E[r].v, O.v);
+                    *(HubRow<NC>*)(grow + c0[0] + g * NC) = O;
+                }
+            }
+        }
+    } else {
+        for (int g = tid; g < NG; g += 256) {
+            float ag[G], bg[G], eg[NC], out[NC];
+#pragma unroll
+            for (int i = 0; i < G; ++i) { ag[i] = arow[1 + g * G + i]; bg[i] = brow[1 + g * G + i]; }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) eg[c] = erow[c0[c] + g * cs];
+            group(ag, bg, eg, out);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) grow[c0[c] + g * cs] = out[c];
         }
     }
     for (int e = tid; e < NX; e += 256) {
@@ -4153,6 +4248,7 @@ struct Plan {
     bool hub = false;       // lin, by sweep_hub_kernel / post_hub_kernel: every graph is in hub form with the same (G, NC)
     int hub_g = -1, hub_nc = 0, hub_ng = 0;   // (-1: no graph seen yet; 0: not all in the same hub form)
     int hub_pat = -2;                         // index into kHubPatterns when every graph has that pattern (-2: none seen, -1: other)
+    int hub_kpf = 0, hub_kpb = 0;             // split ring of sweep_hub_kernel: buffer pitches that hold every graph's parts (-1: some graph has no split)
     size_t off_big = 0, off_Et = 0;
     int64_t nstates = 0;
     int nheavy_in_max = 0, nheavy_out_max = 0;
@@ -4182,7 +4278,7 @@ constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where not
 struct Hooks {
     int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
         zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache,
-        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern, no_tab_kernarg;
+        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern, no_tab_kernarg, no_hub_split, hub_force_split;
 };
 Hooks g_hooks;
 bool g_hooks_loaded = false;
@@ -4205,7 +4301,8 @@ void load_hooks() {
     h.quad_r = env_int("WF_QUAD_R", 0);
     h.no_post_check = env_int("WF_NO_POST_CHECK", 0); h.fill_side_stream = env_int("WF_FILL_SIDE_STREAM", 0);
     h.no_hub = env_int("WF_NO_HUB_SWEEP", 0); h.no_hub_pattern = env_int("WF_NO_HUB_PATTERN", 0);
-    h.no_tab_kernarg = env_int("WF_NO_TAB_KERNARG", 0);
+    h.no_tab_kernarg = env_int("WF_NO_TAB_KERNARG", 0); h.no_hub_split = env_int("WF_NO_HUB_SPLIT", 0);
+    h.hub_force_split = env_int("WF_HUB_FORCE_SPLIT", 0);
     g_hooks = h;
     g_hooks_loaded = true;
 }
@@ -4289,6 +4386,23 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
                     }
                     if (fits && !memcmp(want, cfh, sizeof(float) * 9 * nc)) pat = q;
                 }
+            }
+            if (I[WF_I_HUB_G] > 0 && P->hub_kpf >= 0) {
+                // split ring: tokens of a group consecutive; the largest front part such that three front and two back
+                // buffers fit the LDS
+                const int nc = I[WF_I_HUB_NC], cs = I[WF_I_HUB_CS], K = I[WF_I_K];
+                const int32_t* c0h = H + I[WF_I_HUB_C0];
+                bool inter = cs == nc;
+                for (int c = 1; c < nc; ++c) inter = inter && c0h[c] == c0h[0] + c;
+                int best_f = 0, best_b = 0;
+                for (int k = kHubSlots - 1; k >= 1 && inter && !best_f; --k) {
+                    const int64_t f = (int64_t)c0h[0] + (int64_t)kHubCompute * k * cs;
+                    if (f >= K) continue;
+                    const size_t pf = align_up((size_t)f, 64) + 64, pb = align_up((size_t)(K - f), 64) + 64;
+                    if (kHubLdsFixed + (3 * pf + 2 * pb) * 4 <= kLdsBudget) { best_f = (int)pf; best_b = (int)pb; }
+                }
+                if (!best_f) P->hub_kpf = -1;
+                else { P->hub_kpf = std::max(P->hub_kpf, best_f); P->hub_kpb = std::max(P->hub_kpb, best_b); }
             }
             if (P->hub_g == -1) { P->hub_g = I[WF_I_HUB_G]; P->hub_nc = I[WF_I_HUB_NC]; P->hub_pat = pat; }
             else if (P->hub_g != I[WF_I_HUB_G] || P->hub_nc != I[WF_I_HUB_NC]) P->hub_g = 0;
@@ -4667,8 +4781,16 @@ bool linbig_config(const Plan& P) {
 // hub form (sweep_hub_kernel): every graph of the call, the same (G, NC) instantiation, groups within kHubSlots per
 // compute lane, a probability row within the loader lanes' reach and two of them within the LDS
 size_t hub_kp(const Plan& P) { return align_up((size_t)P.kmax, 64) + 64; }   // a row buffer: whole 64-float DMA pieces
-int hub_nb(const Plan& P) { return 32 * 8 + 32 * 4 + 3 * hub_kp(P) * 4 <= kLdsBudget ? 3 : 2; }
-size_t hub_lds(const Plan& P) { return 32 * 8 + 32 * 4 + (size_t)hub_nb(P) * hub_kp(P) * 4; }
+int hub_nb(const Plan& P) { return kHubLdsFixed + 3 * hub_kp(P) * 4 <= kLdsBudget && !hk().hub_force_split ? 3 : 2; }   // (test hook: rows as if too long for three)
+// rows too long for three buffers: the split ring (three buffers of the front part, two of the back part), when every
+// graph of the call has a split (Plan::hub_kpf / hub_kpb, see hub_split) and the parts fit
+bool hub_is_split(const Plan& P) {
+    return hub_nb(P) == 2 && P.hub_kpf > 0 && !hk().no_hub_split && kHubLdsFixed + (3 * (size_t)P.hub_kpf + 2 * (size_t)P.hub_kpb) * 4 <= kLdsBudget;
+}
+size_t hub_lds(const Plan& P) {
+    if (hub_is_split(P)) return kHubLdsFixed + (3 * (size_t)P.hub_kpf + 2 * (size_t)P.hub_kpb) * 4;
+    return kHubLdsFixed + (size_t)hub_nb(P) * hub_kp(P) * 4;
+}
 bool hub_config(const Plan& P) {
     if (hk().no_hub || hk().no_lin == 1) return false;
     if (P.hub_g < 2 || P.hub_g > WF_HUB_MAX_G || P.hub_nc < 2 || P.hub_nc > 3 || (P.hub_g == 3 && P.hub_nc != 3)) return false;
@@ -4680,6 +4802,8 @@ int launch_sweep_hub_one(const Plan& P, SweepArgs a, int B, hipStream_t st) {
     const size_t lds = hub_lds(P);
     a.kpad = (int)hub_kp(P);
     a.chunk = hub_nb(P);
+    a.hub_kpf = a.hub_kpb = 0;
+    if (hub_is_split(P)) { a.hub_kpf = P.hub_kpf; a.hub_kpb = P.hub_kpb; }
     a.ablate = hk().sweep_ablate;
     auto k = sweep_hub_kernel<G, NC, PAT>;
     { int rc_ = ensure_lds((const void*)k, lds); if (rc_) return rc_; }
