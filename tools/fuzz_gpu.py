@@ -52,6 +52,9 @@ for case in range(n):
             lp2[perm[i], st:st + segs2[i, 2]] = c["lp"][i, :segs2[i, 2]]
             segs2[i, 0], segs2[i, 1] = perm[i], st
         c["lp"], c["segs"] = lp2, segs2
+    only = os.environ.get("FUZZ_ONLY")   # replay one case of a run (the draws above are made for every case)
+    if only is not None and case != int(only):
+        continue
     x = torch.from_numpy(c["lp"]).cuda().requires_grad_(True)
     dense = wf.DenseFsaVec(x, torch.from_numpy(c["segs"]))
     wf.set_output_beam_mode("pruned" if beam else "exact")
@@ -60,8 +63,20 @@ for case in range(n):
     torch.where(fin, loss, torch.zeros_like(loss)).sum().backward()
     want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], beam, "none")
     got, g = loss.detach().cpu().numpy(), x.grad.cpu().numpy()
-    ok = np.allclose(got, want, rtol=1e-4, atol=1e-4) and np.allclose(g, np.where(np.isfinite(wgrad), wgrad, 0), atol=1e-3) \
+    same = lambda w, wg: np.allclose(got, w, rtol=1e-4, atol=1e-4) and np.allclose(g, np.where(np.isfinite(wg), wg, 0), atol=1e-3) \
         and np.all(np.isfinite(g))
+    ok = same(want, wgrad)
+    if not ok and beam:
+        # Lattice arcs whose best path sits on the beam's edge to within the fp32 rounding of the tropical scores (the
+        # oracle prunes in fp64) may fall on either side.  The kept set grows with the beam and the total with the set,
+        # so the result must lie between the oracle's for a beam a hair narrower and a hair wider.
+        eps = 2e-3
+        (wn, gn), (ww, gw) = (o.graphloss(c["ographs"], c["lp"], c["segs"], beam + d, "none") for d in (-eps, eps))
+        z = lambda a: np.where(np.isfinite(a), a, 0)
+        ok = bool(np.all((got <= wn + 1e-4 * np.abs(wn) + 1e-4) & (got >= ww - 1e-4 * np.abs(ww) - 1e-4)) and np.all(np.isfinite(g))
+                  and np.all(np.abs(g - z(wgrad)) <= np.abs(z(gn) - z(gw)).max() + 1e-3))
+        if ok:
+            print("  (case", case, "lies between the oracle's results at beam", beam, "-+", eps, ": arcs on the beam's edge)", flush=True)
     best = wf.best_path(c["fsa"], dense)
     for i, gr in enumerate(c["ographs"]):
         sq, st, tt = (int(v) for v in c["segs"][i])
