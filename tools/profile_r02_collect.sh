@@ -5,6 +5,7 @@ cd "$(dirname "$0")/.." || exit 1
 S=gpurun_out/prof_r02
 cp $S/cfg3_kernel_stats.txt profiles/r02_bench_cfg3_kernel_stats.txt
 cp $S/cfg4den_kernel_stats.txt profiles/r02_bench_cfg4_mmictc_den_kernel_stats.txt
+cp $S/cfg4den3_kernel_stats.txt profiles/r02_bench_cfg4_3state-skip_den_kernel_stats.txt
 cp $S/cfg2den_kernel_stats.txt profiles/r02_bench_cfg2_den_kernel_stats.txt
 cp $S/cfg2num_kernel_stats.txt profiles/r02_bench_cfg2_num_kernel_stats.txt
 cp $S/cfg5_kernel_stats.txt profiles/r02_search_cfg5_S1e6_kernel_stats.txt
