@@ -139,7 +139,9 @@ struct SweepArgs {
     int hub_kpf, hub_kpb;
     int ablate;    // measurement aids, never set by the product path: bit 8 (WF_SWEEP_PROFILE=1) workgroup 0 prints its cycles per
                    // frame step; sweep_kernel, WF_SWEEP_ABLATE: 16 no register copy of streamed arcs, 32 no row stores, 64 no heavy
-                   // states, 128 no light states (32-128 give wrong results: timing only)
+                   // states, 128 no light states (32-128 give wrong results: timing only); sweep_hub_kernel (tools/abl_hub.sh):
+                   // 1 row stores all to row 0, 2 no loads, 4 no per-frame barrier (wrong results: timing only), 32 4-byte
+                   // LDS-DMA pieces only, 64 the general frame body (both with unchanged results)
 };
 
 // arc accessors: CSR arrays either in LDS (packed 16+16) or in global memory
