@@ -69,6 +69,12 @@ extern "C" {
                              grad box is zero-filled on a side stream beside the sweeps, so that the
                              wf_fb_backward(flags | WF_PREZERO, same grad) that follows only scatters the posteriors
                              (the autograd split of loss and gradient without paying for the fill twice over)   */
+#define WF_ACCUMULATE 32u /* wf_fb_logsum with grad != NULL (no counterpart in k2: its gradients meet in autograd): the
+                             gradient box already holds values and this call's gradient is ADDED to them -- nothing is
+                             zero-filled, only the K label columns of each row are touched.  For the numerator of a
+                             numerator - denominator loss (rnnp.py:91-104) after the denominator's call wrote the box:
+                             one buffer, no fill, no addition pass.  Graphs of the probability-domain path with at most
+                             512 states / 1024 arcs (every topo o transcript numerator); others: WF_EUNSUPPORTED.       */
 
 typedef struct {
     int32_t num_fsas;                 /* G                                                     */

@@ -1098,3 +1098,45 @@ def test_label_grad_sums_kernel_matches_torch():
         ref = grad.double().sum((0, 1)).cpu().numpy()
         np.testing.assert_allclose(out[3:], ref, rtol=1e-4, atol=1e-4)
         assert out[1] == 77
+
+
+@pytest.mark.parametrize("reduction", ["sum", "mean", "none"])
+@pytest.mark.parametrize("topo,P", [("2state", 9), ("mmictc", 10), ("3state-skip", 300), ("mmictc", 300), ("2state_sil", 8)])
+def test_graphloss_num_den_equals_the_two_call_form(topo, P, reduction):
+    """graphloss_num_den (one autograd node, one gradient box: the denominator's call writes it, the numerator's adds
+    its K entries per row with WF_ACCUMULATE) against graphloss(num) - graphloss(den) (rnnp.py:64-104) and the oracle;
+    P = 300: the denominator takes the hub kernels."""
+    c = util.random_case(900 + P, topo, B=4, T=37, L=5, P=P)
+    den = wf.create_fsa_vec([c["topo"]] * 4)
+    tl = torch.tensor([len(s) for s in c["seqs"]], dtype=torch.float32)
+    seg = torch.from_numpy(c["segs"])
+    up = torch.tensor([0.5, -2.0, 1.0, 3.0], device=DEV)
+
+    def run(fn):
+        x = torch.from_numpy(c["lp"]).to(DEV).requires_grad_(True)
+        loss = fn(wf.DenseFsaVec(x, seg))
+        (loss * up).sum().backward() if reduction == "none" else (loss * 0.7).backward()
+        return loss.detach().cpu().numpy(), x.grad.cpu().numpy()
+    two = lambda d: (wf.graphloss(c["fsa"], d, reduction=reduction, target_lengths=tl)
+                     - wf.graphloss(den, d, reduction=reduction, target_lengths=tl))
+    one = lambda d: wf.graphloss_num_den(c["fsa"], den, d, reduction=reduction, target_lengths=tl)
+    l2, g2 = run(two)
+    l1, g1 = run(one)
+    np.testing.assert_allclose(l1, l2, rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(g1, g2, atol=2e-5)
+    # and against the oracle (sum): d loss / d lp = - posterior(num) + posterior(den)
+    if reduction == "sum":
+        wn, gn = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "sum")
+        wd, gd = o.graphloss(den.as_oracle_graphs(), c["lp"], c["segs"], None, "sum")
+        np.testing.assert_allclose(l1, wn - wd, rtol=TOT_RTOL, atol=TOT_ATOL)
+        np.testing.assert_allclose(g1, 0.7 * (gn - gd), atol=GRAD_ATOL)
+
+
+def test_accumulate_flag_limits():
+    """WF_ACCUMULATE through the C ABI: refused (WF_EUNSUPPORTED, already by wf_fb_workspace_bytes) for graphs beyond
+    post_small_kernel's reach, and with WF_PRUNED / a missing gradient."""
+    from waterfall_amd import _lib
+    c = util.random_case(31, "mmictc", B=2, T=20, L=3, P=300, den=True)          # a hub-form denominator: not accepted
+    assert not c["fsa"].accumulate_ok(c["segs"], 2, c["V"])
+    n = util.random_case(32, "mmictc", B=2, T=20, L=3, P=300)
+    assert n["fsa"].accumulate_ok(n["segs"], 2, n["V"])

@@ -1,5 +1,7 @@
-"""Drop-in cost of the k2-loss pattern (rnnp.py:91-104): numerator - denominator under autograd, cfg4 mmictc sizes."""
+"""Drop-in cost of the k2-loss pattern (rnnp.py:91-104): numerator - denominator under autograd, cfg4 mmictc sizes;
+the two-call form (eager / split denominators) and graphloss_num_den (one node, one gradient box)."""
 import sys, time
+sys.path.insert(0, ".")
 import numpy as np, torch
 import waterfall_amd as wf
 from waterfall_amd import graph as G
@@ -14,16 +16,19 @@ num = wf.compile_ctc_k2_graphs(topo, seqs)
 den = wf.create_fsa_vec([topo.fsa] * B)
 lp = torch.log_softmax(torch.randn(B, T, V, device=dev) * 3, -1).requires_grad_(True)
 seg = torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32)
-for mode in (True, False):
-    G._EAGER_DIRECT = mode
+for mode in (True, False, "num_den"):
+    G._EAGER_DIRECT = mode is not False
     def step():
         lp.grad = None
         d = wf.DenseFsaVec(lp, seg)
-        loss = wf.graphloss(num, d, reduction="sum") - wf.graphloss(den, d, reduction="sum")
+        if mode == "num_den":
+            loss = wf.graphloss_num_den(num, den, d, reduction="sum")
+        else:
+            loss = wf.graphloss(num, d, reduction="sum") - wf.graphloss(den, d, reduction="sum")
         loss.backward()
         return loss
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): l = step()
     torch.cuda.synchronize()
-    print("eager denominators" if mode else "split denominators", "%.3f ms/step" % ((time.perf_counter() - t0) / 10 * 1e3), float(l), float(lp.grad.abs().sum()))
+    print({True: "eager denominators", False: "split denominators", "num_den": "graphloss_num_den"}[mode], "%.3f ms/step" % ((time.perf_counter() - t0) / 10 * 1e3), float(l.detach()), float(lp.grad.abs().sum()))

@@ -14,6 +14,7 @@ WF_TROPICAL = 2
 WF_KEEP_AB = 4
 WF_PRUNED = 8
 WF_PREZERO = 16
+WF_ACCUMULATE = 32
 
 
 class WfError(RuntimeError):

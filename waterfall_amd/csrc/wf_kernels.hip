@@ -3024,6 +3024,7 @@ struct PostArgs {
     int pass;
     int32_t* flag_w;
     int force;  // test hook (WF_FORCE_FALLBACK): pass 0 flags every utterance
+    int accum;  // WF_ACCUMULATE (post_small_kernel): the posteriors are added to what the rows hold
 };
 
 // log2(v) + add for a scaled probability of the linear sweep (0 -> -inf)
@@ -3614,7 +3615,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
             if (lane + i * 64 < K && !((heavy[i] >> lane) & 1)) {
                 float acc = 0.f;
                 for (int a = k0[i]; a < k1[i]; ++a) acc += lpost[a];
-                if (acc != 0.f || store_zeros) grow[klab[i]] = gs * acc;
+                if (acc != 0.f || store_zeros) grow[klab[i]] = p.accum ? grow[klab[i]] + gs * acc : gs * acc;
             }
             unsigned long long hm = heavy[i];
             while (hm) {   // wave-uniform
@@ -3624,7 +3625,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
                 float acc = 0.f;
                 for (int a = a0 + lane; a < a1; a += 64) acc += lpost[a];
                 acc = wave_sum(acc);
-                if (lane == hl && (acc != 0.f || store_zeros)) grow[klab[i]] = gs * acc;
+                if (lane == hl && (acc != 0.f || store_zeros)) grow[klab[i]] = p.accum ? grow[klab[i]] + gs * acc : gs * acc;
             }
         }
         __builtin_amdgcn_wave_barrier();   // la / lb / le / lpost are rewritten by the next frame
@@ -4985,6 +4986,9 @@ extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2
     int rc = plan_fb(graph_host, utt2fsa, seg, B, V, num_seqs, need_grad || (flags & (WF_KEEP_AB | WF_PRUNED)),
                      (flags & WF_DOUBLE_ACC) != 0, (flags & WF_PRUNED) != 0, &P, &fwd_via_fb);
     if (rc) return rc;
+    // (asked with WF_ACCUMULATE: also says whether wf_fb_logsum will take the flag for these graphs)
+    if ((flags & WF_ACCUMULATE) && (!P.lin || P.hub || !post_small_fits(P)))
+        return wf_fail(WF_EUNSUPPORTED, "wf_fb_workspace_bytes: WF_ACCUMULATE is for graphs of the probability-domain path with at most 512 states / 1024 arcs (numerators)");
     *bytes = P.total + 256;
     return WF_OK;
 }
@@ -5119,8 +5123,9 @@ int launch_zero(float* grad, int64_t strideB, int64_t strideT, int num_seqs, int
 // pass: PostArgs::pass (-1: check_kernel ran before; 0: post_small_kernel checks the rows itself)
 int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                 int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
-                float* grad, bool skip_zero, hipStream_t st, int pass = -1) {
+                float* grad, bool skip_zero, hipStream_t st, int pass = -1, bool accum = false) {
     PostArgs q{};
+    q.accum = accum ? 1 : 0;
     q.pass = pass; q.flag_w = (int32_t*)(ws + P.off_flag); q.force = hk().force_fallback;
     {
         int grp = 0, lag = 0;
@@ -5245,9 +5250,18 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = g_tm.have_check = false;
     // Fork: zero-fill the gradient box on the side stream while the sweeps (which occupy only 2B
     // workgroups) run; post_kernel then only scatters the K posteriors per row.
-    const bool overlap = grad && P.any_compact && !hk().no_overlap;
+    // WF_ACCUMULATE: the box holds another call's gradient -- no fill, and the posteriors are added once the rows are
+    // final (check_kernel and the fallback first: a row check folded into the scatter could not take its additions back)
+    const bool accum = flags & WF_ACCUMULATE;
+    if (accum) {
+        if (!grad || pruned || (flags & (WF_PREZERO | WF_KEEP_AB)))
+            return wf_fail(WF_EINVAL, "wf_fb_logsum: WF_ACCUMULATE goes with grad != NULL and none of WF_PRUNED / WF_PREZERO / WF_KEEP_AB");
+        if (!P.lin || P.hub || !post_small_fits(P))
+            return wf_fail(WF_EUNSUPPORTED, "wf_fb_logsum: WF_ACCUMULATE is for graphs of the probability-domain path with at most 512 states / 1024 arcs (numerators)");
+    }
+    const bool overlap = grad && P.any_compact && !hk().no_overlap && !accum;
     // the row check folded into post_small_kernel (no check_kernel launch): when the gradient is computed by this call
-    const bool postcheck = P.lin && grad && !(flags & WF_PREZERO) && !hk().no_post_check &&
+    const bool postcheck = P.lin && grad && !(flags & WF_PREZERO) && !hk().no_post_check && !accum &&
                            (P.hub || ((overlap || !P.any_compact) && post_small_fits(P)));
     ForkGuard guard(st);   // every return below first makes `st` wait for the side stream
     if ((rc = tm_record(0, st))) return rc;
@@ -5406,7 +5420,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     } else if (grad) {
         if ((rc = guard.wait())) return rc;
         if ((rc = tm_record(3, st))) return rc;
-        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st);
+        rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap || accum, st, -1, accum);
         if (rc) return rc;
         if ((rc = tm_record(4, st))) return rc;
         g_tm.have_post = g_tm.on;

@@ -164,6 +164,24 @@ class Fsa:
             v = self._all_compact = bool((b[HDR_WORDS + INFO["DIRECT"]:HDR_WORDS + INFO_WORDS * self.num_fsas:INFO_WORDS] == 0).all())
         return v
 
+    def all_direct(self):
+        """True when every FSA's label columns are the labels themselves (a topology over the whole table: a denominator),
+        i.e. its gradient rows are dense."""
+        v = getattr(self, "_all_direct", None)
+        if v is None:
+            from .csrc_layout import HDR_WORDS, INFO_WORDS, INFO
+            b = self.blob_host()
+            v = self._all_direct = bool((b[HDR_WORDS + INFO["DIRECT"]:HDR_WORDS + INFO_WORDS * self.num_fsas:INFO_WORDS] != 0).all())
+        return v
+
+    def accumulate_ok(self, seg, num_seqs, V):
+        """Will wf_fb_logsum take WF_ACCUMULATE for these graphs (numerators of the probability-domain path)?"""
+        try:
+            self.workspace_bytes(seg, num_seqs, V, _lib.WF_ACCUMULATE, True)
+            return True
+        except _lib.WfError:
+            return False
+
     def workspace_bytes(self, seg, num_seqs, V, flags, need_grad):
         """wf_fb_workspace_bytes, cached per (segments, N, V, flags): a training loop asks with the same values twice per
         step (numerator graphs are new objects every step; a denominator topology is asked thousands of times)."""
