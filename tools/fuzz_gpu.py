@@ -83,6 +83,24 @@ for case in range(n):
         s, path = o.viterbi(gr, c["lp"][sq, st:st + tt], tt)
         if best["scores"][i].item() != s and not (np.isinf(s) and np.isinf(best["scores"][i].item())):
             ok = False
+    if ok and not den and not beam and c["topo"] is not None and rng.integers(2):
+        # the numerator - denominator pair as one node (WF_ACCUMULATE) against the two-call form, same inputs
+        dg = wf.create_fsa_vec([c["topo"]] * B)
+        res = []
+        for fn in (lambda d: wf.graphloss_num_den(c["fsa"], dg, d, reduction="sum"),
+                   lambda d: wf.graphloss(c["fsa"], d, reduction="sum") - wf.graphloss(dg, d, reduction="sum")):
+            x2 = torch.from_numpy(c["lp"]).cuda().requires_grad_(True)
+            l2 = fn(wf.DenseFsaVec(x2, torch.from_numpy(c["segs"])))
+            if torch.isfinite(l2):
+                (l2 * -1.5).backward()
+            res.append((l2.item(), None if x2.grad is None else x2.grad.cpu().numpy()))
+        (la, ga), (lb, gb) = res
+        if np.isfinite(lb):
+            ok = bool(np.isclose(la, lb, rtol=1e-5, atol=1e-3) and np.allclose(ga, gb, atol=2e-5))
+        else:
+            ok = not np.isfinite(la) or np.isnan(la) == np.isnan(lb)
+        if not ok:
+            print("  (graphloss_num_den differs from the two-call form)", la, lb, flush=True)
     if not ok:
         bad += 1
         print("MISMATCH", case, topo, den, B, T, L, P, env, beam, np.abs(got - want).max(),
