@@ -479,6 +479,45 @@ def search_bench(dev, S, B=8, T=500, V=5001, beam=20.0, max_active=10000, reps=3
                     f"max_active_states={max_active}, peaked synthetic posterior; wall time of wf.pruned_search incl. host"}
 
 
+def num_den_bench(dev, B=32, T=500, P=5000, L=64, reps=10):
+    """The numerator - denominator loss of the reference's k2 branch (rnnp.py:64-104) at cfg4 mmictc sizes under
+    autograd: graphloss(num) - graphloss(den) (what the reference's lines do, unchanged) beside graphloss_num_den
+    (one node, one gradient box: WF_ACCUMULATE).  Wall time per loss + backward step, resident graphs."""
+    phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
+    topo = wf.Topology("mmictc", phones)
+    V = topo.num_nn_output
+    rng = np.random.default_rng(777)
+    num = wf.compile_ctc_k2_graphs(topo, [[int(x) + 2 for x in rng.integers(0, P, size=L)] for _ in range(B)])
+    den = wf.create_fsa_vec([topo.fsa] * B)
+    gen = torch.Generator(device=dev).manual_seed(777)
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=gen, device=dev) * 3.0, -1).requires_grad_(True)
+    seg = torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32)
+    out = {}
+    for name in ("two_call", "num_den"):
+        def step():
+            lp.grad = None
+            d = wf.DenseFsaVec(lp, seg)
+            if name == "num_den":
+                loss = wf.graphloss_num_den(num, den, d, reduction="sum")
+            else:
+                loss = wf.graphloss(num, d, reduction="sum") - wf.graphloss(den, d, reduction="sum")
+            loss.backward()
+            return loss
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            l = step()
+        torch.cuda.synchronize()
+        out[name + "_ms_per_step"] = (time.perf_counter() - t0) / reps * 1e3
+        out[name + "_loss"] = float(l.detach())
+        out[name + "_grad_abs_sum"] = float(lp.grad.abs().sum())
+    out["desc"] = f"mmictc numerators (L={L}) - denominators (S={2 * (P + 1) + 2}), V={V}, B={B}, T={T}, reduction=sum, loss + backward under autograd"
+    out["checked_by"] = "tests/test_gpu_parity.py::test_graphloss_num_den_equals_the_two_call_form"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -676,6 +715,11 @@ def main():
                 others["cfg5_search_S1e+06_beam20"] = search_bench(dev, 1_000_000)
             except Exception as e:   # noqa: BLE001
                 others["cfg5_search_S1e+06_beam20"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            try:
+                others["cfg4_mmictc_num_minus_den_autograd"] = num_den_bench(dev)
+            except Exception as e:   # noqa: BLE001
+                others["cfg4_mmictc_num_minus_den_autograd"] = {"error": repr(e)}
             torch.cuda.empty_cache()
             out["other_workloads"] = others
         print(json.dumps(out))

@@ -19,6 +19,9 @@ for line in open(sys.argv[1]):
         if "error" in v:
             print(f"   {k:28s} ERROR {v['error']}")
             continue
+        if "num_den_ms_per_step" in v:
+            print(f"   {k:28s} two calls {v['two_call_ms_per_step']:.3f} ms/step, graphloss_num_den {v['num_den_ms_per_step']:.3f} ms/step")
+            continue
         if "speedup_vs_exact" in v:
             print(f"   {k:28s} {v['ms_per_call']:.3f} ms/call ({v['ms_per_call_with_log_total']:.3f} with log total)  exact sweep {v['exact_sweep_ms_per_call']:.3f} ms  x{v['speedup_vs_exact']:.2f}  same path {v['same_path']}")
             continue
