@@ -74,7 +74,10 @@ extern "C" {
                              zero-filled, only the K label columns of each row are touched.  For the numerator of a
                              numerator - denominator loss (rnnp.py:91-104) after the denominator's call wrote the box:
                              one buffer, no fill, no addition pass.  Graphs of the probability-domain path with at most
-                             512 states / 1024 arcs (every topo o transcript numerator); others: WF_EUNSUPPORTED.       */
+                             512 states / 1024 arcs (every topo o transcript numerator); others: WF_EUNSUPPORTED (asked
+                             with the flag, wf_fb_workspace_bytes says so beforehand).  Also taken by wf_fb_backward after a
+                             wf_fb_logsum(WF_KEEP_AB, grad == NULL): the numerator's sweeps may then run on another stream
+                             beside the denominator's.                                                                   */
 
 typedef struct {
     int32_t num_fsas;                 /* G                                                     */

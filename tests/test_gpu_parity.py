@@ -1124,6 +1124,12 @@ def test_graphloss_num_den_equals_the_two_call_form(topo, P, reduction):
     l1, g1 = run(one)
     np.testing.assert_allclose(l1, l2, rtol=2e-5, atol=2e-4)
     np.testing.assert_allclose(g1, g2, atol=2e-5)
+    wf.set_num_den_overlap(True)     # the numerator's sweeps on a side stream (wf_fb_logsum(WF_KEEP_AB) + wf_fb_backward(WF_ACCUMULATE))
+    try:
+        l3, g3 = run(one)
+    finally:
+        wf.set_num_den_overlap(False)
+    assert np.array_equal(l3, l1) and np.array_equal(g3, g1)
     # and against the oracle (sum): d loss / d lp = - posterior(num) + posterior(den)
     if reduction == "sum":
         wn, gn = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "sum")

@@ -5684,7 +5684,11 @@ extern "C" int wf_fb_backward(const void* graph_host, const void* graph_dev, con
     // P.lin repeats the decision the forward call made; the fallback flags are still in the workspace
     // WF_PREZERO: the forward call zero-filled the box under exactly the condition below (its `overlap`)
     const bool prezeroed = (flags & WF_PREZERO) && P.any_compact && !hk().no_overlap;
-    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, prezeroed, st);
+    // WF_ACCUMULATE: the box holds another call's gradient; this call's posteriors are added (see wf_fb_logsum)
+    const bool accum = flags & WF_ACCUMULATE;
+    if (accum && ((flags & (WF_PRUNED | WF_PREZERO)) || !P.lin || P.hub || !post_small_fits(P)))
+        return wf_fail(WF_EUNSUPPORTED, "wf_fb_backward: WF_ACCUMULATE is for graphs of the probability-domain path with at most 512 states / 1024 arcs (numerators), without WF_PRUNED / WF_PREZERO");
+    rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, prezeroed || accum, st, -1, accum);
     if (rc) return rc;
     if ((rc = tm_record(4, st))) return rc;
     g_tm.have_post = g_tm.on;

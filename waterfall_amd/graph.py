@@ -183,6 +183,25 @@ class _EagerLossFunction(torch.autograd.Function):
         return grad, None, None, None, None
 
 
+_NUMDEN_OVERLAP = False
+_SIDE = {}
+
+
+def set_num_den_overlap(on: bool):
+    """graphloss_num_den: run the numerator's sweeps on a side stream beside the denominator's (they join before the
+    numerator's posteriors are added).  Off by default: 1.81 -> 1.75 ms per step at cfg4 sizes is little for a second
+    stream inside an autograd node (not capturable in a HIP graph as is)."""
+    global _NUMDEN_OVERLAP
+    _NUMDEN_OVERLAP = bool(on)
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev.index)
+    if s is None:
+        s = _SIDE[dev.index] = torch.cuda.Stream(dev)
+    return s
+
+
 class _NumDenFunction(torch.autograd.Function):
     """graphloss(numerator) - graphloss(denominator) on one DenseFsaVec (the 'k2' loss, rnnp.py:64-104) as ONE autograd
     node with ONE gradient buffer: the denominator's fused call writes every entry of the box, the numerator's adds its K
@@ -198,7 +217,8 @@ class _NumDenFunction(torch.autograd.Function):
         N, T, V = lp.shape
         # (two workspaces: backward scales the box through the denominator's tables -- dense rows -- which the numerator's
         # call must not overwrite)
-        nb_num, nb_den = num.workspace_bytes(seg, N, V, 0, True), den.workspace_bytes(seg, N, V, 0, True)
+        nb_num = num.workspace_bytes(seg, N, V, _lib.WF_KEEP_AB if _NUMDEN_OVERLAP else 0, True)
+        nb_den = den.workspace_bytes(seg, N, V, 0, True)
         ws_num = torch.empty(nb_num, dtype=torch.uint8, device=dev)
         ws_den = torch.empty(nb_den, dtype=torch.uint8, device=dev)
         tots = torch.empty(2, B, dtype=torch.float32, device=dev)
@@ -206,12 +226,29 @@ class _NumDenFunction(torch.autograd.Function):
         w = weights if weights is not None else _const(dev, B, 1.0)       # loss = sum_b w_b (tot_den_b - tot_num_b)
         wneg = w.neg() if weights is not None else _const(dev, B, -1.0)
         st = _stream(dev)
+
+        def call(g, gscale, tot, flags, gr, ws, nbytes, stream):
+            _lib.check(lib.wf_fb_logsum(_np_ptr(g.blob_host()), _ptr(g.blob_dev(dev)), _np_ptr(g.utt2fsa), _ptr(lp),
+                                        lp.stride(0), lp.stride(1), N, T, V, _np_ptr(seg), B, 0.0, flags, _ptr(gscale),
+                                        _ptr(tot), _ptr(gr) if gr is not None else None, _ptr(ws), nbytes, stream))
         with _on(dev):
-            for g, gscale, tot, flags, ws, nbytes in ((den, w, tots[1], 0, ws_den, nb_den),
-                                                      (num, wneg, tots[0], _lib.WF_ACCUMULATE, ws_num, nb_num)):
-                _lib.check(lib.wf_fb_logsum(_np_ptr(g.blob_host()), _ptr(g.blob_dev(dev)), _np_ptr(g.utt2fsa), _ptr(lp),
-                                            lp.stride(0), lp.stride(1), N, T, V, _np_ptr(seg), B, 0.0, flags, _ptr(gscale),
-                                            _ptr(tot), _ptr(grad), _ptr(ws), nbytes, st))
+            if _NUMDEN_OVERLAP:
+                # the numerator's sweeps (2B small workgroups) on a side stream beside the denominator's (2B workgroups
+                # that own a CU each): they meet again before the numerator's posteriors are added to the box
+                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                side.wait_stream(main)
+                for t in (lp, ws_num, tots):
+                    t.record_stream(side)
+                call(num, wneg, tots[0], _lib.WF_KEEP_AB, None, ws_num, nb_num, C.c_void_p(side.cuda_stream))
+                call(den, w, tots[1], 0, grad, ws_den, nb_den, st)
+                main.wait_stream(side)
+                _lib.check(lib.wf_fb_backward(_np_ptr(num.blob_host()), _ptr(num.blob_dev(dev)), _np_ptr(num.utt2fsa), _ptr(lp),
+                                              lp.stride(0), lp.stride(1), N, T, V, _np_ptr(seg), B,
+                                              _lib.WF_KEEP_AB | _lib.WF_ACCUMULATE, _ptr(wneg), _ptr(tots[0]), _ptr(grad),
+                                              _ptr(ws_num), nb_num, st))
+            else:
+                call(den, w, tots[1], 0, grad, ws_den, nb_den, st)
+                call(num, wneg, tots[0], _lib.WF_ACCUMULATE, grad, ws_num, nb_num, st)
         per_utt = (tots[1] - tots[0]) * w if weights is not None else tots[1] - tots[0]
         loss = per_utt if reduction == 'none' else per_utt.sum()
         ctx.grad = grad
