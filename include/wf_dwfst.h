@@ -98,6 +98,13 @@ const char* wf_last_error(void);
 int wf_init(void);
 int wf_shutdown(void);
 int wf_debug_reload_env(void);
+/* Test aid (no counterpart in the reference): the number of utterances of the last wf_fb_logsum call on `workspace` that
+ * were redone by the log-semiring fallback (rows of the probability-domain sweep that failed the row check).  Arguments
+ * as for wf_fb_workspace_bytes of that call; synchronises `stream`.  Tests use it to tell a kernel that is right from
+ * one whose mistakes the fallback repairs.                                                                          */
+int wf_debug_fallback_count(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B,
+                            int32_t num_seqs, int32_t V, uint32_t flags, int32_t need_grad,
+                            const void* workspace, size_t workspace_bytes, void* stream, int32_t* count);
 
 /* ---- graph preparation (host only, no GPU needed) ------------------------------------------
  * Builds the position-independent "prepared graph": per FSA the incoming-arc CSR (forward sweep),

@@ -281,6 +281,10 @@ def test_full_size_against_c_oracle_and_properties(oracle_lib, topo, P, L, den):
         np.testing.assert_allclose(grad[b, :T].sum(-1), -1.0, atol=2e-3)   # posteriors of one frame sum to 1
         assert np.all(grad[b, T:] == 0)
     assert np.all(grad <= 0)
+    tot, fgrad = fused_logsum(c["fsa"], c["lp"], c["segs"])
+    assert LAST_FALLBACKS[0] == 0          # the probability-domain kernels' own rows: nothing was redone in the log semiring
+    np.testing.assert_allclose(-tot, -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(fgrad, grad_d, atol=GRAD_ATOL)
 
 
 def test_full_size_mmictc_denominator_properties(oracle_lib):
@@ -296,6 +300,10 @@ def test_full_size_mmictc_denominator_properties(oracle_lib):
                                         use_double=True, nthreads=2)
     np.testing.assert_allclose(loss[:2], -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(grad[:2], grad_d, atol=GRAD_ATOL)
+    tot_f, grad_f = fused_logsum(c["fsa"], c["lp"], c["segs"])
+    assert LAST_FALLBACKS[0] == 0          # sweep_hub_kernel's rows passed the check: no utterance was redone
+    np.testing.assert_allclose(-tot_f[:2], -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad_f[:2], grad_d, atol=GRAD_ATOL)
     # default: probability-domain sweep_linbig_kernel.  The other implementations on the same batch: the
     # log-semiring sweep with this thread's arcs in registers / re-read from memory in every frame (same
     # arithmetic in the same order: bit-identical), the LDS-staged gradient kernel, the per-frame-launch sweep,
@@ -346,8 +354,13 @@ SWEEP_PATHS = {
 }
 
 
+LAST_FALLBACKS = [None]   # fused_logsum: utterances of the last call that the log-semiring fallback redid
+
+
 def fused_logsum(fsa, lp, segs, gscale=-1.0):
-    """wf_fb_logsum with grad != NULL (loss + gradient in one call: the path bench.py times)."""
+    """wf_fb_logsum with grad != NULL (loss + gradient in one call: the path bench.py times).  Leaves the number of
+    utterances the fallback redid in LAST_FALLBACKS[0] (a kernel whose rows fail the check is repaired by it: tests
+    of a probability-domain kernel assert 0)."""
     import ctypes as C
     from waterfall_amd import _lib
     lib = _lib.lib()
@@ -367,6 +380,9 @@ def fused_logsum(fsa, lp, segs, gscale=-1.0):
     st = C.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
     _lib.check(lib.wf_fb_logsum(npp(gh), p(gd), npp(fsa.utt2fsa), p(x), x.stride(0), x.stride(1), N, T, V, npp(segs), B,
                                 0.0, 0, p(gs), p(tot), p(grad), p(ws), n.value, st))
+    cnt = C.c_int32(-1)
+    _lib.check(lib.wf_debug_fallback_count(npp(gh), npp(fsa.utt2fsa), npp(segs), B, N, V, 0, 1, p(ws), n.value, st, C.byref(cnt)))
+    LAST_FALLBACKS[0] = cnt.value
     torch.cuda.synchronize()
     return tot.cpu().numpy(), grad.cpu().numpy()
 
@@ -415,10 +431,13 @@ def test_sweep_paths_fused_and_autograd(path, topo, den, L, T, P):
 
     def run():
         tot, grad = fused_logsum(c["fsa"], c["lp"], c["segs"])
+        nfb = LAST_FALLBACKS[0]
         loss, agrad = run_hip(c["fsa"], c["lp"], c["segs"], "none")
         loss2, agrad2 = run_hip(c["fsa"], c["lp"], c["segs"], "none", eager=False)
-        return tot, grad, loss, agrad, loss2, agrad2
-    tot, grad, loss, agrad, loss2, agrad2 = _with_env(SWEEP_PATHS[path], run)
+        return tot, grad, loss, agrad, loss2, agrad2, nfb
+    tot, grad, loss, agrad, loss2, agrad2, nfb = _with_env(SWEEP_PATHS[path], run)
+    # the kernel under test delivered the rows itself (a wrong row fails the check and the fallback repairs it silently)
+    assert (nfb >= ok.sum()) if "fallback" in path else (nfb == 0)   # (forced: every feasible utterance is redone)
     for got_loss, got_grad in ((-tot, grad), (loss, agrad), (loss2, agrad2)):
         assert np.array_equal(np.isfinite(got_loss), ok)
         np.testing.assert_allclose(got_loss[ok], want[ok], rtol=TOT_RTOL, atol=TOT_ATOL)
@@ -439,25 +458,27 @@ def test_sweep_paths_weighted_arcs(path):
     fsa = util.graphs_to_fsa(graphs)
     want, wgrad = o.graphloss(graphs, c["lp"], c["segs"], None, "none")
     tot, grad = _with_env(SWEEP_PATHS[path], lambda: fused_logsum(fsa, c["lp"], c["segs"]))
+    assert "fallback" in path or LAST_FALLBACKS[0] == 0   # (weighted arcs: some of the forced paths have no probability-domain sweep to fall back from)
     np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
 
 
 def test_linear_sweep_underflow_is_caught_by_the_row_check():
-    # A forced alignment through labels ~900 nats below each frame's best label in the first half of
-    # the utterance: the probability-domain sweeps lose those states (fp64 underflow after rescaling to
-    # the row maximum is impossible here, but exp(lp - c_t) of the needed labels is 0), the row identity
-    # fails, and the log-semiring fallback must deliver the exact result.
+    # Every path must start through labels ~900 nats below the frame's best label AMONG THE GRAPH'S OWN (the model
+    # insists on the transcript's last label from the first frame on; c_t is the maximum over the graph's K columns):
+    # exp(lp - c_t) of the labels the first frames need is 0, the probability-domain sweep dies, the row identity
+    # fails, and the log-semiring fallback must deliver the exact result -- for that utterance only.
     topo, tokens = wf.build_topology("ctc", util.ctc_phones(6))
     fsa = wf.compile_ctc_k2_graphs(topo, [[1, 2, 3], [2, 2]])
     T, V = 40, len(tokens)
     lp = np.full((2, T, V), -900.0, dtype=np.float32)
-    lp[:, :, 4] = 0.0          # the model insists on a label that is not in either transcript
+    lp[:, :, 3] = 0.0          # label 3 ends the first transcript: reachable only after labels 1 and 2 at -900 each
     lp[1, :, :] = np.log(1.0 / V)   # the second utterance is ordinary
     segs = np.array([[0, 0, T], [1, 0, T]], dtype=np.int32)
     want, wgrad = o.graphloss(fsa.as_oracle_graphs(), lp, segs, None, "none")
-    assert np.isfinite(want).all() and want[0] > 30000
+    assert np.isfinite(want).all() and want[0] > 1500
     tot, grad = fused_logsum(fsa, lp, segs)
+    assert LAST_FALLBACKS[0] == 1          # the first utterance only
     np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
     loss, agrad = run_hip(fsa, lp, segs, "none")
@@ -975,6 +996,10 @@ def test_full_size_3state_skip_denominator_properties(oracle_lib):
                                         use_double=True, nthreads=2)
     np.testing.assert_allclose(loss[:2], -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(grad[:2], grad_d, atol=GRAD_ATOL)
+    tot_f, grad_f = fused_logsum(c["fsa"], c["lp"], c["segs"])
+    assert LAST_FALLBACKS[0] == 0          # sweep_hub_kernel (split ring at this V) delivered the rows itself
+    np.testing.assert_allclose(-tot_f[:2], -tot_d, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad_f[:2], grad_d, atol=GRAD_ATOL)
     run = lambda: run_hip(c["fsa"], c["lp"], c["segs"], "none")
     lg, gg = _with_env({"WF_NO_LINBIG_SWEEP": "1"}, run)          # log-semiring sweep on the same batch
     np.testing.assert_allclose(lg, loss, rtol=1e-6)
@@ -1059,6 +1084,8 @@ def test_hub_form_denominators(topo, path):
             fwd, _ = run_hip(c["fsa"], c["lp"], c["segs"], "none", need_grad=False)
         return tot, grad, loss, agrad, fwd
     tot, grad, loss, agrad, fwd = _with_env(HUB_PATHS[path], run)
+    nfb = _with_env(HUB_PATHS[path], lambda: (fused_logsum(c["fsa"], c["lp"], c["segs"]), LAST_FALLBACKS[0])[1])
+    assert nfb == (4 if "fallback" in path else 0)          # the hub / linbig kernels' own rows passed the check
     for got_loss, got_grad in ((-tot, grad), (loss, agrad)):
         np.testing.assert_allclose(got_loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
         np.testing.assert_allclose(got_grad, wgrad, atol=GRAD_ATOL)
@@ -1078,6 +1105,7 @@ def test_hub_split_ring(topo, P):
     want, wgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], None, "none")
     run = lambda: fused_logsum(c["fsa"], c["lp"], c["segs"])
     tot, grad = _with_env({"WF_HUB_FORCE_SPLIT": "1"}, run)
+    assert LAST_FALLBACKS[0] == 0
     np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
     tot2, grad2 = _with_env({"WF_HUB_FORCE_SPLIT": "1", "WF_NO_HUB_SPLIT": "1"}, run)      # two whole-row buffers
@@ -1146,3 +1174,30 @@ def test_accumulate_flag_limits():
     assert not c["fsa"].accumulate_ok(c["segs"], 2, c["V"])
     n = util.random_case(32, "mmictc", B=2, T=20, L=3, P=300)
     assert n["fsa"].accumulate_ok(n["segs"], 2, n["V"])
+
+
+def test_hub_form_with_more_self_loop_labels_than_compute_lanes():
+    """A hub-form graph whose hub has 901 self-loop labels outside the groups (more than sweep_hub_kernel's 768 compute
+    lanes take one each): the 2state topology over 400 phones plus 900 filler labels looping on state 0."""
+    from waterfall_amd.csrc_layout import HDR_WORDS, INFO_WORDS
+    c = util.random_case(41, "2state", B=3, T=31, L=4, P=400, den=True)
+    g = c["ographs"][0]
+    V0 = c["V"]
+    extra = 900
+    k = 1                                               # after the hub's own first arc (its blank self-loop)
+    ins = lambda a, vals: np.concatenate([a[:k], vals, a[k:]])
+    g2 = {"src": ins(g["src"], np.zeros(extra, np.int32)), "dst": ins(g["dst"], np.zeros(extra, np.int32)),
+          "label": ins(g["label"], np.arange(V0, V0 + extra, dtype=np.int32)),
+          "score": ins(g["score"], np.zeros(extra, np.float32)), "aux": ins(g["aux"], np.arange(V0, V0 + extra, dtype=np.int32)),
+          "num_states": g["num_states"]}
+    V = V0 + extra
+    gen = torch.Generator().manual_seed(5)
+    lp = torch.log_softmax(torch.randn(3, 31, V, generator=gen) * 3.0, -1).numpy()
+    fsa = util.graphs_to_fsa([g2] * 3)
+    info = fsa.blob_host()[HDR_WORDS:HDR_WORDS + INFO_WORDS]
+    assert info[46] == 2 and info[47] == 400 and info[52] == extra + 1          # WF_I_HUB_G / NG / NX
+    want, wgrad = o.graphloss([g2] * 3, lp, c["segs"], None, "none")
+    tot, grad = _with_env({"WF_NO_LIN_SWEEP": "2"}, lambda: fused_logsum(fsa, lp, c["segs"]))
+    assert LAST_FALLBACKS[0] == 0
+    np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)

@@ -53,6 +53,7 @@ _SIGS = {
     "wf_init": (C.c_int, []),
     "wf_shutdown": (C.c_int, []),
     "wf_debug_reload_env": (C.c_int, []),
+    "wf_debug_fallback_count": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, _i32, _p, _sz, _p, C.POINTER(_i32)]),
     "wf_numerator_compile": (C.c_int, [_p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _i32, _p, _p, C.c_int64, _p, _p,
                                        _p, _sz, C.POINTER(_sz), _i32]),
     "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),

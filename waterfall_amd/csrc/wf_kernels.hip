@@ -1893,6 +1893,10 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
                 }
             }
             if (tid < NX) selfd += (double)__builtin_amdgcn_exp2f(fmaf((xc < Kf || ksplit == kHubSlots ? pc : pcb)[xc], kLog2e, shf));
+            for (int e = tid + kHubCompute; e < NX; e += kHubCompute) {   // (more hub self-loop labels than compute lanes: no reference topology has them)
+                const int c2 = xcol[e];
+                selfd += (double)__builtin_amdgcn_exp2f(fmaf((c2 < Kf || ksplit == kHubSlots ? pc : pcb)[c2], kLog2e, shf));
+            }
             part = fma(h, selfd, part);
             if (shr) { asm volatile(""); part = ldexp(part, shr); }
             part = wave_sum_d(part);
@@ -4990,6 +4994,29 @@ extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2
     if ((flags & WF_ACCUMULATE) && (!P.lin || P.hub || !post_small_fits(P)))
         return wf_fail(WF_EUNSUPPORTED, "wf_fb_workspace_bytes: WF_ACCUMULATE is for graphs of the probability-domain path with at most 512 states / 1024 arcs (numerators)");
     *bytes = P.total + 256;
+    return WF_OK;
+}
+
+// Test aid: how many utterances of the last wf_fb_logsum call on this workspace were redone by the log-semiring fallback
+// (their probability-domain rows failed the row check, or WF_FORCE_FALLBACK).  Same (graph, seg, V, num_seqs, flags,
+// need_grad) as that call.  Synchronises the stream.
+extern "C" int wf_debug_fallback_count(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B,
+                                       int32_t num_seqs, int32_t V, uint32_t flags, int32_t need_grad,
+                                       const void* workspace, size_t workspace_bytes, void* stream, int32_t* count) {
+    if (!workspace || !count) return wf_fail(WF_EINVAL, "wf_debug_fallback_count: null pointer");
+    Plan P;
+    bool fwd_via_fb = false;
+    int rc = plan_fb(graph_host, utt2fsa, seg, B, V, num_seqs, need_grad || (flags & (WF_KEEP_AB | WF_PRUNED)),
+                     (flags & WF_DOUBLE_ACC) != 0, (flags & WF_PRUNED) != 0, &P, &fwd_via_fb);
+    if (rc) return rc;
+    const unsigned char* ws = (const unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (ws + P.total > (const unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small");
+    *count = 0;
+    if (!P.lin) return WF_OK;   // (no probability-domain sweep, nothing to fall back from)
+    std::vector<int32_t> f(B);
+    HIP_TRY(hipMemcpyAsync(f.data(), ws + P.off_flag, sizeof(int32_t) * B, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < B; ++i) *count += f[i] != 0;
     return WF_OK;
 }
 
