@@ -182,6 +182,14 @@ class Workload:
                                     _ptr(self.gscale), _ptr(self.tot), _ptr(self.grad), _ptr(self.ws),
                                     self.ws_bytes, C.c_void_p(stream)))
 
+    def fallbacks(self, stream):
+        """Utterances of the last step that the log-semiring fallback redid (0: the timed path is the probability-domain
+        kernels' own work, not a repair of it)."""
+        n = C.c_int32(-1)
+        _lib.check(_lib.lib().wf_debug_fallback_count(_np(self.gh), _np(self.fsa.utt2fsa), _np(self.segs), self.B, self.B, self.V,
+                                                      0, 1, _ptr(self.ws), self.ws_bytes, C.c_void_p(stream), C.byref(n)))
+        return int(n.value)
+
     # ---- algorithmic bytes (DESIGN.md "Kernels"): what each kernel must move, per batch --------
     def kernel_bytes(self, lin=False):
         V = self.V
@@ -609,6 +617,7 @@ def main():
                    "parallelism": (f"batch-sharded x{world}, one fused all-reduce per step of [loss_sum, n_frames, n_infeasible"
                                    + (f", {wl.V} per-label gradient sums]" if grad_sums else "]")) if world > 1 else "single GPU"},
         "arc_updates_per_sec": 2 * total_arcs / (dt / args.steps),
+        "fallback_utterances": wl.fallbacks(stream),
     }
     if rank == 0:
         kt = kernel_times(wl, stream)
@@ -699,6 +708,7 @@ def main():
                     k2 = kernel_times(w2, stream, reps=5)
                     k2["fill_in_sweep"] = bool(k2["fill_in_sweep"])
                     others[name] = {"frames_per_s": w2.frames / (d2 / n2), "ms_per_step": d2 / n2 * 1e3,
+                                    "fallback_utterances": w2.fallbacks(stream),
                                     "arc_updates_per_sec": 2 * w2.arc_updates / (d2 / n2), "kernels_ms": k2,
                                     "desc": WORKLOADS[name]["desc"]}
                     del w2
