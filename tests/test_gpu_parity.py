@@ -1201,3 +1201,29 @@ def test_hub_form_with_more_self_loop_labels_than_compute_lanes():
     assert LAST_FALLBACKS[0] == 0
     np.testing.assert_allclose(-tot, want, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(grad, wgrad, atol=GRAD_ATOL)
+
+
+def test_graphloss_num_den_falls_back_to_the_two_call_form():
+    """Where the fused pair does not apply -- no gradient wanted, the "pruned" beam mode -- graphloss_num_den is the
+    two-call expression itself."""
+    c = util.random_case(61, "2state", B=3, T=30, L=4, P=7)
+    den = wf.create_fsa_vec([c["topo"]] * 3)
+    seg = torch.from_numpy(c["segs"])
+    x = torch.from_numpy(c["lp"]).to(DEV)
+    with torch.no_grad():
+        d = wf.DenseFsaVec(x, seg)
+        a = wf.graphloss_num_den(c["fsa"], den, d, reduction="none")
+        b = wf.graphloss(c["fsa"], d, reduction="none") - wf.graphloss(den, d, reduction="none")
+    assert torch.equal(a, b) and not a.requires_grad
+    wf.set_output_beam_mode("pruned")
+    try:
+        res = []
+        for fn in (lambda d: wf.graphloss_num_den(c["fsa"], den, d, output_beam=6.0),
+                   lambda d: wf.graphloss(c["fsa"], d, output_beam=6.0) - wf.graphloss(den, d, output_beam=6.0)):
+            xg = x.clone().requires_grad_(True)
+            l = fn(wf.DenseFsaVec(xg, seg))
+            l.backward()
+            res.append((l.item(), xg.grad.clone()))
+    finally:
+        wf.set_output_beam_mode("exact")
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
