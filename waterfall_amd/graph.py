@@ -138,7 +138,14 @@ class _EagerLossFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         tot = torch.empty(B, dtype=torch.float32, device=dev)
         grad = torch.empty_like(lp) if lp.is_contiguous() else torch.empty_strided(lp.shape, lp.stride(), dtype=torch.float32, device=dev)
-        gscale = weights if weights is not None else _const(dev, B, -1.0)      # d loss / d tot_b
+        # The kept gradient is d loss / d log_probs times the upstream factor this node EXPECTS: +1, but -1 for graphs
+        # with dense gradient rows (a denominator: `numerator - denominator`, rnnp.py:100) -- backward's scaling pass over
+        # the box (0.26 ms at cfg4 sizes) is then skipped in the usual case instead of paid in it.
+        expect = -1.0 if graph.all_direct() else 1.0
+        if weights is not None:
+            gscale = weights if expect == 1.0 else weights.neg()               # d loss / d tot_b (x expect)
+        else:
+            gscale = _const(dev, B, -expect)
         st = _stream(dev)
         with _on(dev):
             _lib.check(lib.wf_fb_logsum(_np_ptr(gh), _ptr(gd), _np_ptr(graph.utt2fsa), _ptr(lp), lp.stride(0), lp.stride(1),
@@ -154,6 +161,7 @@ class _EagerLossFunction(torch.autograd.Function):
         # everything backward needs is marshalled here, on the caller's thread: Python on the autograd engine's thread
         # runs several times slower (measured: 42 -> 16 us per backward)
         ctx.keep = (graph, dense, ws, gscale, seg, gd)
+        ctx.expect = expect
         ctx.grad = grad
         ctx.call = [_np_ptr(gh), _ptr(gd), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, N, T, V, lp.stride(0), lp.stride(1), None,
                     1 if reduction == 'none' else 0, _ptr(grad), _ptr(ws), nbytes, st]
@@ -165,6 +173,8 @@ class _EagerLossFunction(torch.autograd.Function):
         grad, ctx.grad = ctx.grad, None
         call = ctx.call
         gs = gout if (gout.dtype == torch.float32 and gout.is_contiguous()) else gout.to(torch.float32).contiguous()
+        if ctx.expect != 1.0:
+            gs = gs.neg()   # relative to the factor the kept gradient already carries
         # (the engine runs this node with the forward's device and stream current)
         if grad is None:   # a second backward through a retained graph: the kept gradient was handed out, compute it again
             graph, dense, ws, gscale, seg, gd = ctx.keep
@@ -206,7 +216,7 @@ class _NumDenFunction(torch.autograd.Function):
     """graphloss(numerator) - graphloss(denominator) on one DenseFsaVec (the 'k2' loss, rnnp.py:64-104) as ONE autograd
     node with ONE gradient buffer: the denominator's fused call writes every entry of the box, the numerator's adds its K
     entries per row (WF_ACCUMULATE: no zero-fill, no second box, no addition pass -- under autograd the two-call form
-    pays a x(-1) pass over the denominator's box and the sum of two boxes, 0.6 ms of 2.7 at cfg4 sizes)."""
+    pays the numerator's fill and the sum of two boxes, 0.4 ms of 2.2 at cfg4 sizes)."""
 
     @staticmethod
     def forward(ctx, log_probs, num, den, dense, reduction, weights):
