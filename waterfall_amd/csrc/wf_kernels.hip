@@ -5571,10 +5571,20 @@ __global__ void __launch_bounds__(256) label_sums_kernel(const float* grad, int6
     const int c0 = blockIdx.x * 1024 + threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * kLabelRows, r1 = min(r0 + kLabelRows, (int64_t)N * T);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t r = r0; r < r1; ++r) {
-        const float* row = grad + (r / T) * strideB + (r % T) * strideT;
+    // four rows per round: sixteen independent loads in flight per lane (one row at a time left the kernel at 3.2 TB/s)
+    for (int64_t r = r0; r < r1; r += 4) {
+        float v[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int c = c0 + j * 256; if (c < V) acc[j] += row[c]; }
+        for (int i = 0; i < 4; ++i) {
+            const int64_t rr = min(r + i, r1 - 1);
+            const float* row = grad + (rr / T) * strideB + (rr % T) * strideT;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int c = c0 + j * 256; v[i][j] = (c < V && r + i < r1) ? row[c] : 0.f; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v[i][j];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int c = c0 + j * 256; if (c < V && acc[j] != 0.f) atomicAdd(out + c, acc[j]); }
