@@ -5304,7 +5304,22 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     // 128-lane fill workgroups in the sweep's launch: ~80 GB/s each, sized to end with the sweep (~0.095 us per frame step).
     // More of them slow the chain waves down (measured on cfg3, ms per step: 32 -> 0.177, 44 -> 0.144, 68 -> 0.112,
     // 80 -> 0.1037, 100 -> 0.1044, 124 -> 0.110, 180 -> 0.119)
-    int nfill_sweep = (int)((double)num_seqs * Tmax * V * 4.0 / (std::max(P.Tlong, 1) * 0.095e-6) / 80e9) + 1;
+    // (the chain's time per frame step beside the fill, by instantiation: <3,2> cfg3 0.095 us; four rows per lane <4,2>
+    // 0.16 us, distance-4 bands <4,4> 0.19 us, the general-graph mode 0.17 us -- a fill sized for a faster chain than
+    // the launch has crowds the memory pipeline and slows the chain further: cfg4's mmictc numerators 555 cycles per
+    // step with 169 fill workgroups against 378 alone)
+    // Measured on cfg4's numerators (V = 10 001 / 15 001, ms per step by fill workgroups): mmictc 84 -> 0.175, 96 -> 0.164,
+    // 112 -> 0.155, 128 -> 0.168, 169 -> 0.191; 3state-skip 112 -> 0.235, 128 -> 0.227, 160 -> 0.231, side stream 0.258.
+    // Beside these slower chains a fill workgroup reaches ~62 GB/s, ~120 of them saturate the HBM, and the launch does
+    // best with a whole number of workgroups per XCD.
+    const BandSel bsf = band_config(P);
+    const bool slow_chain = bsf.ok && (bsf.gen || bsf.BW == 4 || bsf.R == 4);
+    const double step_s = !slow_chain ? 0.095e-6 : bsf.gen ? 0.17e-6 : bsf.BW == 4 ? 0.19e-6 : 0.16e-6;
+    int nfill_sweep = (int)((double)num_seqs * Tmax * V * 4.0 / (std::max(P.Tlong, 1) * step_s) / (slow_chain ? 62e9 : 80e9)) + 1;
+    if (slow_chain) {
+        nfill_sweep = std::min(nfill_sweep, 128);
+        nfill_sweep += (8 - (2 * B + nfill_sweep) % 8) % 8;
+    }
     nfill_sweep = std::max(16, nfill_sweep);
     if (hk().zero_blocks > 0) nfill_sweep = 2 * hk().zero_blocks;
     const bool fill_in_sweep = overlap && P.lin && band_config(P).ok && flat && !hk().fill_side_stream && !hk().zero_memset &&
