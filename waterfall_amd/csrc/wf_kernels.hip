@@ -1810,8 +1810,18 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
                         v.v[i] = nv[i];
                         eb = max(eb, __builtin_bit_cast(unsigned, nv[i]));
                     }
-                    const int g = tid + k * kHubCompute;
-                    if (k < NS - 1 || g < NG) *(HubRow<G>*)(srow + 1 + g * G) = v;
+                const int g = tid + k * kHubCompute;
+                    if (k < NS - 1 || g < NG) {
+                        // (streaming: the rows are read again only by the posterior kernel, after the whole sweep)
+                        if constexpr (G == 2) {
+                            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                            f2u w2 = {v.v[0], v.v[1]};
+                            __builtin_nontemporal_store(w2, (f2u*)(srow + 1 + g * G));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < G; ++i) __builtin_nontemporal_store(v.v[i], srow + 1 + g * G + i);
+                        }
+                    }
                 }
                 part += (double)part32;
                 selfd += (double)self32;
@@ -3429,7 +3439,7 @@ __global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
                 if (g < NG) {
                     HubRow<NC> O;
                     group(A[r].v, Bv[r].v, E[r].v, O.v);
-                    *(HubRow<NC>*)(grow + c0[0] + g * NC) = O;
+                    *(HubRow<NC>*)(grow + c0[0] + g * NC) = O;   // (a non-temporal store here costs 7 %: measured)
                 }
             }
         }
