@@ -2705,7 +2705,7 @@ __global__ void __launch_bounds__(256) big_step_shared_kernel(BigSharedArgs p) {
 #pragma unroll
         for (int j = 0; j < kNB; ++j) {
             out[j] = act[j] ? (TROP ? m[j] : lse_value(m[j], sm[j])) : keep[j];
-            if (bprow[j]) bprow[j][s] = (m[j] == neg_inf<Acc>()) ? -1 : barc[j];
+            if (bprow[j]) __builtin_nontemporal_store((m[j] == neg_inf<Acc>()) ? -1 : barc[j], bprow[j] + s);   // (read once, by the back-trace)
         }
 #pragma unroll
         for (int j = 0; j < kNB; ++j) nxt[(int64_t)s * kNB + j] = out[j];
