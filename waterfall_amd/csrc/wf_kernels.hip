@@ -2946,7 +2946,8 @@ struct GatherLinTabArgs {
 };
 static_assert(sizeof(GatherLinTabArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-template <bool TAB, typename Args>
+// NK: columns per lane (2: rows of at most 128 columns; 4: at most 256 -- cfg4's numerators have K = 2 L + 1 = 129)
+template <bool TAB, int NK, typename Args>
 __device__ __forceinline__ void gather_lin_small_body(const Args& a) {
     const GatherLinArgs& p = [&]() -> const GatherLinArgs& { if constexpr (TAB) return a.g; else return a; }();
     const int lane = threadIdx.x;
@@ -2967,15 +2968,18 @@ __device__ __forceinline__ void gather_lin_small_body(const Args& a) {
     const int K = (int)U(WF_U_K), direct = (int)U(WF_U_DIRECT);
     const int32_t* labels = p.blob + U(WF_U_LABELS);
     const float* row0 = p.lp + U(WF_U_SEQ) * p.strideB + (U(WF_U_START) + t0) * p.strideT;
-    const int k0 = lane, k1 = lane + 64;
-    const int c0 = k0 < K ? (direct ? k0 : labels[k0]) : 0;
-    const int c1 = k1 < K ? (direct ? k1 : labels[k1]) : 0;
-    float v0[kGFR], v1[kGFR];
+    int col[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const int k = lane + 64 * j;
+        col[j] = k < K ? (direct ? k : labels[k]) : 0;
+    }
+    float v[kGFR][NK];
 #pragma unroll
     for (int r = 0; r < kGFR; ++r) {
         const float* row = row0 + (int64_t)min(r, T - 1 - t0) * p.strideT;   // frames past T re-read the last one (not stored)
-        v0[r] = row[c0];
-        v1[r] = row[c1];
+#pragma unroll
+        for (int j = 0; j < NK; ++j) v[r][j] = row[col[j]];
     }
     const int64_t pp = U(WF_U_PP);
     double* prow = p.P + U(WF_U_P) + (int64_t)t0 * pp;
@@ -2984,17 +2988,24 @@ __device__ __forceinline__ void gather_lin_small_body(const Args& a) {
 #pragma unroll
     for (int r = 0; r < kGFR; ++r) {
         if (t0 + r >= T) break;
-        const float x = k0 < K ? v0[r] : -INFINITY, y = k1 < K ? v1[r] : -INFINITY;
-        float m = wave_max(fmaxf(x, y));
+        float x[NK], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) { x[j] = lane + 64 * j < K ? v[r][j] : -INFINITY; mx = fmaxf(mx, x[j]); }
+        float m = wave_max(mx);
         if (!(m > -INFINITY)) m = 0.f;   // every label impossible in this frame: P = 0
-        if (k0 < K) { prow[r * pp + k0] = exp((double)x - (double)m); if (!direct) erow[r * K + k0] = x; }
-        if (k1 < K) { prow[r * pp + k1] = exp((double)y - (double)m); if (!direct) erow[r * K + k1] = y; }
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            const int k = lane + 64 * j;
+            if (k < K) { prow[r * pp + k] = exp((double)x[j] - (double)m); if (!direct) erow[r * K + k] = x[j]; }
+        }
         if (lane == 0) crow[r] = (double)m;
     }
 }
 
-__global__ void __launch_bounds__(64) gather_lin_small_kernel(GatherLinArgs p) { gather_lin_small_body<false>(p); }
-__global__ void __launch_bounds__(64) gather_lin_small_tab_kernel(GatherLinTabArgs p) { gather_lin_small_body<true>(p); }
+__global__ void __launch_bounds__(64) gather_lin_small_kernel(GatherLinArgs p) { gather_lin_small_body<false, 2>(p); }
+__global__ void __launch_bounds__(64) gather_lin_small_tab_kernel(GatherLinTabArgs p) { gather_lin_small_body<true, 2>(p); }
+__global__ void __launch_bounds__(64) gather_lin_small4_kernel(GatherLinArgs p) { gather_lin_small_body<false, 4>(p); }
+__global__ void __launch_bounds__(64) gather_lin_small4_tab_kernel(GatherLinTabArgs p) { gather_lin_small_body<true, 4>(p); }
 
 // ------------------------------------------------------------------------------------------
 // posterior / gradient rows
@@ -5085,7 +5096,7 @@ int build_seq2utt(const int32_t* seg, int B, int num_seqs, std::vector<int32_t>*
 // The per-call tables can ride in the arguments of gather_lin_small_tab_kernel (see there) when that kernel opens the
 // call, the batch is small, every table word fits 32 bits and every sequence of log_probs is named by a segment.
 bool tab_in_kernarg(const Plan& P, int num_seqs, bool want_seq2utt) {
-    if (hk().no_tab_kernarg || !P.lin || P.hub || P.linbig || P.kmax > 128 || hk().no_gather_small) return false;
+    if (hk().no_tab_kernarg || !P.lin || P.hub || P.linbig || P.kmax > 256 || hk().no_gather_small) return false;
     if (P.B > kTabMaxB || (want_seq2utt && num_seqs != P.B)) return false;
     for (int64_t v : P.utt) if (v < 0 || v > 0x7fffffff) return false;
     return true;
@@ -5102,9 +5113,13 @@ int launch_gather(const Plan& P, const void* graph_dev, unsigned char* ws, const
             GatherLinTabArgs a;
             a.g = g; a.utt_out = (int64_t*)(ws + P.off_utt); a.seq2utt_out = tab_seq2utt ? (int32_t*)(ws + P.off_seq2utt) : nullptr;
             for (size_t i = 0; i < P.utt.size(); ++i) a.tab.w[i] = (int32_t)P.utt[i];
-            hipLaunchKernelGGL(gather_lin_small_tab_kernel, dim3((std::max(P.Tlong, 1) + kGFR - 1) / kGFR, P.B), dim3(64), 0, st, a);
+            const dim3 grid((std::max(P.Tlong, 1) + kGFR - 1) / kGFR, P.B);
+            if (P.kmax <= 128) hipLaunchKernelGGL(gather_lin_small_tab_kernel, grid, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(gather_lin_small4_tab_kernel, grid, dim3(64), 0, st, a);
         } else if (!P.linbig && P.kmax <= 128 && !hk().no_gather_small)
             hipLaunchKernelGGL(gather_lin_small_kernel, dim3((std::max(P.Tlong, 1) + kGFR - 1) / kGFR, P.B), dim3(64), 0, st, g);
+        else if (!P.linbig && P.kmax <= 256 && !hk().no_gather_small)
+            hipLaunchKernelGGL(gather_lin_small4_kernel, dim3((std::max(P.Tlong, 1) + kGFR - 1) / kGFR, P.B), dim3(64), 0, st, g);
         else
             hipLaunchKernelGGL(gather_lin_kernel, dim3(std::max(P.Tlong, 1), P.B), dim3(64), 0, st, g);
         HIP_TRY(hipGetLastError());
