@@ -297,7 +297,7 @@ def kernel_times(wl, stream, reps=20):
     if kt["zero"] < 0 and kt["check"] >= 0:
         old = os.environ.get("WF_FILL_SIDE_STREAM")
         os.environ["WF_FILL_SIDE_STREAM"] = "1"
-        lib.wf_debug_reload_env()
+        _lib.reload_env()
         try:
             kt["zero"] = run()["zero"]
         finally:
@@ -305,7 +305,7 @@ def kernel_times(wl, stream, reps=20):
                 os.environ.pop("WF_FILL_SIDE_STREAM", None)
             else:
                 os.environ["WF_FILL_SIDE_STREAM"] = old
-            lib.wf_debug_reload_env()
+            _lib.reload_env()
     return kt
 
 

@@ -249,10 +249,12 @@ int wf_state_posteriors(const void* graph_host, const void* graph_dev, const int
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- total scores only, log or tropical (lattice_analysis.py:128-129) ------------------------
- * tot: device fp32 [B] (or fp64 [B] when WF_DOUBLE_ACC is set).                                 */
+ * tot: device fp32 [B] (or fp64 [B] when WF_DOUBLE_ACC is set).  num_seqs / Tmax: the first two dimensions of
+ * log_probs; every compute entry point checks each segment against them (WF_ERANGE) before anything is launched.
+ * Workspace: wf_fb_workspace_bytes(flags, need_grad = 0) with the same num_seqs.                 */
 int wf_tot_scores(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
-                  const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
-                  const int32_t* seg, int32_t B, uint32_t flags, void* tot,
+                  const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t Tmax,
+                  int32_t V, const int32_t* seg, int32_t B, uint32_t flags, void* tot,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- tropical best path (k2.shortest_path / one_best_decoding) -------------------------------
@@ -262,7 +264,7 @@ int wf_tot_scores(const void* graph_host, const void* graph_dev, const int32_t* 
 int wf_viterbi_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
                                int32_t B, int32_t V, uint32_t flags, size_t* bytes);
 int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
-               const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
+               const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V,
                const int32_t* seg, int32_t B, int32_t Tmax, uint32_t flags, float* best_score,
                int32_t* best_arcs, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -279,7 +281,7 @@ int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt
 int wf_search_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B, int32_t V,
                               int32_t max_active_states, int32_t want_log_tot, size_t* bytes);
 int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
-              int64_t strideB, int64_t strideT, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
+              int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
               float search_beam, int32_t min_active_states, int32_t max_active_states, uint32_t flags,
               float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
               size_t workspace_bytes, void* stream);

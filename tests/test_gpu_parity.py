@@ -357,10 +357,10 @@ SWEEP_PATHS = {
 LAST_FALLBACKS = [None]   # fused_logsum: utterances of the last call that the log-semiring fallback redid
 
 
-def fused_logsum(fsa, lp, segs, gscale=-1.0):
+def fused_logsum(fsa, lp, segs, gscale=-1.0, beam=0.0):
     """wf_fb_logsum with grad != NULL (loss + gradient in one call: the path bench.py times).  Leaves the number of
     utterances the fallback redid in LAST_FALLBACKS[0] (a kernel whose rows fail the check is repaired by it: tests
-    of a probability-domain kernel assert 0)."""
+    of a probability-domain kernel assert 0).  beam > 0: output_beam pruning (WF_PRUNED)."""
     import ctypes as C
     from waterfall_amd import _lib
     lib = _lib.lib()
@@ -372,16 +372,17 @@ def fused_logsum(fsa, lp, segs, gscale=-1.0):
     p = lambda t: C.c_void_p(t.data_ptr())
     npp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
     n = C.c_size_t(0)
-    _lib.check(lib.wf_fb_workspace_bytes(npp(gh), npp(fsa.utt2fsa), npp(segs), B, N, V, 0, 1, C.byref(n)))
+    fl = _lib.WF_PRUNED if beam > 0 else 0
+    _lib.check(lib.wf_fb_workspace_bytes(npp(gh), npp(fsa.utt2fsa), npp(segs), B, N, V, fl, 1, C.byref(n)))
     ws = torch.empty(n.value, dtype=torch.uint8, device=DEV)
     tot = torch.empty(B, dtype=torch.float32, device=DEV)
     grad = torch.full_like(x, 7.0)   # every element must be overwritten
     gs = torch.full((B,), gscale, dtype=torch.float32, device=DEV)
     st = C.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
     _lib.check(lib.wf_fb_logsum(npp(gh), p(gd), npp(fsa.utt2fsa), p(x), x.stride(0), x.stride(1), N, T, V, npp(segs), B,
-                                0.0, 0, p(gs), p(tot), p(grad), p(ws), n.value, st))
+                                float(beam), fl, p(gs), p(tot), p(grad), p(ws), n.value, st))
     cnt = C.c_int32(-1)
-    _lib.check(lib.wf_debug_fallback_count(npp(gh), npp(fsa.utt2fsa), npp(segs), B, N, V, 0, 1, p(ws), n.value, st, C.byref(cnt)))
+    _lib.check(lib.wf_debug_fallback_count(npp(gh), npp(fsa.utt2fsa), npp(segs), B, N, V, fl, 1, p(ws), n.value, st, C.byref(cnt)))
     LAST_FALLBACKS[0] = cnt.value
     torch.cuda.synchronize()
     return tot.cpu().numpy(), grad.cpu().numpy()
@@ -393,7 +394,7 @@ def _with_env(env, fn):
     from waterfall_amd import _lib
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
-    _lib.lib().wf_debug_reload_env()
+    _lib.reload_env()
     try:
         return fn()
     finally:
@@ -402,7 +403,7 @@ def _with_env(env, fn):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-        _lib.lib().wf_debug_reload_env()
+        _lib.reload_env()
 
 
 SWEEP_CASES = [

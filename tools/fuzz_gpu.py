@@ -41,7 +41,7 @@ for case in range(n):
             del os.environ[k]
     os.environ.update(env)
     from waterfall_amd import _lib
-    _lib.lib().wf_debug_reload_env()   # the library reads the hooks once per process
+    _lib.reload_env()   # the library reads the hooks once per process
     if rng.integers(2):   # start offsets, unused sequences, permuted sequence indices
         N, pad = B + int(rng.integers(0, 3)), int(rng.integers(0, 6))
         lp2 = np.log(np.full((N, T + pad, c["V"]), 1.0 / c["V"], dtype=np.float32))

@@ -67,13 +67,13 @@ _SIGS = {
     "wf_loss_reduce": (C.c_int, [_p, _p, _i32, _p, _p]),
     "wf_grad_scale": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i64, _i64, _p, _i32, _p, _p, _sz, _p]),
     "wf_state_posteriors": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _u32, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
-    "wf_tot_scores": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _u32, _p, _p, _sz, _p]),
+    "wf_tot_scores": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, _u32, _p, _p, _sz, _p]),
     "wf_timing_enable": (C.c_int, [C.c_int]),
     "wf_timing_read": (C.c_int, [C.POINTER(C.c_float)]),
     "wf_viterbi_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _u32, C.POINTER(_sz)]),
-    "wf_viterbi": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _i32, _u32, _p, _p, _p, _sz, _p]),
+    "wf_viterbi": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _u32, _p, _p, _p, _sz, _p]),
     "wf_search_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, C.POINTER(_sz)]),
-    "wf_search": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _i32, C.c_float, _i32, _i32, _u32, _p, _p, _p, _p,
+    "wf_search": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, C.c_float, _i32, _i32, _u32, _p, _p, _p, _p,
                             _p, _sz, _p]),
 }
 
@@ -98,6 +98,17 @@ def lib():
 def check(rc):
     if rc != 0:
         raise WfError(f"libwfdwfst error {rc}: {lib().wf_last_error().decode()}")
+
+
+ENV_EPOCH = 0
+
+
+def reload_env():
+    """Test aid: make the library re-read its WF_* environment hooks (read once per process otherwise) and invalidate
+    the Python-side caches of plan-dependent sizes (Fsa.workspace_bytes)."""
+    global ENV_EPOCH
+    ENV_EPOCH += 1
+    return lib().wf_debug_reload_env()
 
 
 def exported_symbols():

@@ -27,7 +27,7 @@
 static thread_local char g_err[512] = "";
 
 extern "C" const char* wf_last_error(void) { return g_err; }
-extern "C" int wf_version(void) { return 1; }
+extern "C" int wf_version(void) { return 2; }
 
 int wf_fail(int code, const char* fmt, ...) {
     va_list ap;

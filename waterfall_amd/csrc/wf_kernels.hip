@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include <type_traits>
@@ -137,6 +138,10 @@ struct SweepArgs {
     // sweep_hub_kernel, split ring (rows too long for three whole LDS buffers): pitch of the three buffers of a row's
     // front part and of the two buffers of its back part, in floats; 0: `chunk` whole-row buffers of pitch kpad
     int hub_kpf, hub_kpb;
+    // banded path with output_beam pruning: keep-mask words [2 directions][bmask_rows][64] (band_mask_kernel -> the MASK
+    // instantiations of sweep_band_kernel), one row per (utterance, frame) in WF_U_ROW0 order
+    unsigned long long* bmask;
+    int64_t bmask_rows;
     int ablate;    // measurement aids, never set by the product path: bit 8 (WF_SWEEP_PROFILE=1) workgroup 0 prints its cycles per
                    // frame step; sweep_kernel, WF_SWEEP_ABLATE: 16 no register copy of streamed arcs, 32 no row stores, 64 no heavy
                    // states, 128 no light states (32-128 give wrong results: timing only); sweep_hub_kernel (tools/abl_hub.sh):
@@ -1973,7 +1978,11 @@ constexpr size_t kBandPBytes = (size_t)kBandC * kBandKP * 8;          // one chu
 constexpr size_t kBandLdsUsed = 2 * kBandPBytes + 2 * 64 * 4 + 16;    // + per-lane exponents (x2) + shift words
 // Requested: more than half of the CU's 160 KiB, so that no two sweep workgroups share a CU (two chain waves
 // on one SIMD would halve each other's issue rate; there are only 2B workgroups for 256 CUs)
-constexpr size_t kBandLds = kBandLdsUsed > 84 * 1024 ? kBandLdsUsed : 84 * 1024;
+constexpr size_t kBandMBytes = (size_t)kBandC * 64 * 8;               // one chunk of staged keep-mask words (MASK)
+constexpr size_t kBandMaskOff = (kBandLdsUsed + 15) & ~(size_t)15;
+constexpr size_t kBandLdsMask = kBandMaskOff + 2 * kBandMBytes;
+constexpr size_t kBandLds = kBandLdsMask > 84 * 1024 ? kBandLdsMask : 84 * 1024;
+constexpr int kBandMaskKMax = kBandKP - 4;   // MASK: columns shifted by two, the pair store of an odd K's pad column included
 
 // MM: arcs per (position, distance) cell (1: deterministic topologies); WE: every arc weight is 0 and
 // MM == 1, so a cell's probability is the staged emission itself (no multiply)
@@ -1981,10 +1990,16 @@ constexpr size_t kBandLds = kBandLdsUsed > 84 * 1024 ? kBandLdsUsed : 84 * 1024;
 // state of up to 64 (the small denominators: cfg2's 2state topology, S = 60, hub fan-in 59).  lane = state; a lane
 // fetches its sources' values with ds_bpermute instead of the DPP shift, the hub's arcs sit one per lane and are
 // summed with the DPP tree.  Stager, chunking, rescaling and the total are the banded kernel's.
-template <int R, int BW, int MM, bool WE, bool GEN = false>
+// MASK (output_beam pruning, see trop_band_kernel / band_mask_kernel below): the stager also stages one 64-bit word per
+// lane and frame whose bit j*MM + m says whether the lattice arc of cell (j, m) survives the beam; a pruned cell reads
+// the zero that sits at offset 0 of every staged row (its LDS address is ANDed with the sign-extended bit: two VALU
+// instructions per cell, off the dependent chain), so the staged columns start 16 bytes into the row.
+template <int R, int BW, int MM, bool WE, bool GEN = false, bool MASK = false>
 __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
     constexpr int GD = WF_REG_DEG;
     constexpr int NQ = GEN ? GD + 1 : R * (BW + 1), C = kBandC;
+    constexpr unsigned ZSH = MASK ? 16u : 0u;   // byte offset of column 0 inside a staged row
+    static_assert(NQ * MM <= 64, "one 64-bit mask word per lane and frame");
     static_assert(MM >= 1 && MM <= WF_BAND_MAX_M && (!WE || MM == 1), "cell capacity");
     static_assert(BW <= R, "sources must sit in the same lane or the previous one");
     static_assert(!GEN || (R == 1 && BW == 1 && MM == 1), "general-graph mode: one state per lane");
@@ -2065,7 +2080,7 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
                 const int arc = j < GD ? a0 + j : h0 + lane;
                 const bool on = j < GD ? j < deg : h0 + lane < h1;
                 gsrc[j] = on ? g_oth[arc] : 0;
-                coff[j][0] = (unsigned)(on ? g_col[arc] : K) * 8u;
+                coff[j][0] = MASK ? (on ? (unsigned)g_col[arc] * 8u + ZSH : 0u) : (unsigned)(on ? g_col[arc] : K) * 8u;
                 cw[j][0] = on ? exp((double)g_w[arc]) : 0.0;
             }
         }
@@ -2084,7 +2099,7 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
                     col = (w == -INFINITY) ? K : ent[0];   // an unused slot of the cell
                     if (w == -INFINITY) w = 0.f;
                 }
-                coff[j][m] = (unsigned)col * 8u;
+                coff[j][m] = MASK ? (col == K ? 0u : (unsigned)col * 8u + ZSH) : (unsigned)col * 8u;
                 cw[j][m] = exp((double)w);
             }
         }
@@ -2095,15 +2110,27 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         const int64_t sstep = dir ? -(int64_t)S : (int64_t)S;
         const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
         // q[j] = probability of cell j in the frame at row k of the staged chunk
-        auto load_q = [&](const unsigned char* pb, const int k, double (&q)[NQ]) __attribute__((always_inline)) {
+        // mb: the chunk's staged mask words (MASK), row k = this frame's
+        auto load_q = [&](const unsigned char* pb, const unsigned char* mb, const int k, double (&q)[NQ]) __attribute__((always_inline)) {
+            int mlo = 0, mhi = 0;
+            if (MASK) {
+                mlo = *(const int*)(mb + (size_t)k * 512 + lane * 8);
+                if (NQ * MM > 32) mhi = *(const int*)(mb + (size_t)k * 512 + lane * 8 + 4);
+            }
+            // byte offset of cell (j, m)'s value inside the staged row: a pruned cell reads the zero at offset 0
+            auto off = [&](const int j, const int m) __attribute__((always_inline)) -> unsigned {
+                if (!MASK) return coff[j][m];
+                const int bit = j * MM + m;
+                return coff[j][m] & (unsigned)__builtin_amdgcn_sbfe(bit < 32 ? mlo : mhi, bit & 31, 1);
+            };
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 if (WE) {
-                    q[j] = *(const double*)(pb + (size_t)k * kBandKP * 8 + coff[j][0]);
+                    q[j] = *(const double*)(pb + (size_t)k * kBandKP * 8 + off(j, 0));
                 } else {
-                    double v = cw[j][0] * *(const double*)(pb + (size_t)k * kBandKP * 8 + coff[j][0]);
+                    double v = cw[j][0] * *(const double*)(pb + (size_t)k * kBandKP * 8 + off(j, 0));
 #pragma unroll
-                    for (int m = 1; m < MM; ++m) v = fma(cw[j][m], *(const double*)(pb + (size_t)k * kBandKP * 8 + coff[j][m]), v);
+                    for (int m = 1; m < MM; ++m) v = fma(cw[j][m], *(const double*)(pb + (size_t)k * kBandKP * 8 + off(j, m)), v);
                     q[j] = v;
                 }
             }
@@ -2153,14 +2180,15 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         for (int c = 0; c < nfull; ++c) {   // full chunks: straight-line steps, probabilities read one step ahead
             __syncthreads();   // the rows of chunk c are staged
             const unsigned char* pb = smem + (size_t)(c & 1) * kBandPBytes;
+            const unsigned char* mb = smem + kBandMaskOff + (size_t)(c & 1) * kBandMBytes;
             double q0[NQ], q1[NQ];
-            load_q(pb, 0, q0);
+            load_q(pb, mb, 0, q0);
             open_chunk(c);
 #pragma unroll
             for (int k = 0; k < C; k += 2) {
-                load_q(pb, k + 1, q1);
+                load_q(pb, mb, k + 1, q1);
                 step(q0);
-                if (k + 2 < C) load_q(pb, k + 2, q0);
+                if (k + 2 < C) load_q(pb, mb, k + 2, q0);
                 step(q1);
             }
             {   // this lane's largest exponent, for the stager's next rescale decision
@@ -2173,11 +2201,12 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         if (nfull < nc) {   // the last, partial chunk
             __syncthreads();
             const unsigned char* pb = smem + (size_t)(nfull & 1) * kBandPBytes;
+            const unsigned char* mb = smem + kBandMaskOff + (size_t)(nfull & 1) * kBandMBytes;
             open_chunk(nfull);
             const int nk = T - nfull * C;
             for (int k = 0; k < nk; ++k) {
                 double q0[NQ];
-                load_q(pb + (size_t)k * kBandKP * 8, 0, q0);
+                load_q(pb + (size_t)k * kBandKP * 8, mb + (size_t)k * 512, 0, q0);
                 step(q0);
             }
         }
@@ -2228,30 +2257,44 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         // Two register sets: the rows of a chunk are loaded two chunks before they are staged (the measured
         // load-to-use latency here is ~2 us, more than one chunk of the chain wave's time).
         d2 preA[C][KVMAX], preB[C][KVMAX];
-        auto issue = [&](const int c, d2 (&pre)[C][KVMAX]) __attribute__((always_inline)) {
+        // MASK: this lane's keep-mask word of every frame of the chunk rides along (band_mask_kernel wrote them, one row
+        // of 64 words per frame and direction); without rows to read (no arcs / empty segment) the table again
+        constexpr int CM = MASK ? C : 1;
+        unsigned long long mkA[CM], mkB[CM];
+        const unsigned long long* mbase = nullptr;
+        if (MASK) mbase = has_p ? p.bmask + ((int64_t)dir * p.bmask_rows + uni(U[WF_U_ROW0])) * 64 + lane : (const unsigned long long*)U;
+        const int64_t mpitch = has_p ? 64 : 0;
+        auto issue = [&](const int c, d2 (&pre)[C][KVMAX], unsigned long long (&mk)[CM]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < C; ++k) {
                 const int s = min(c * C + k, last_step);   // frames past the end repeat the last one
                 const char* row = (const char*)(pbase + (int64_t)(dir ? T - 1 - s : s) * ppitch);   // scalar
 #pragma unroll
                 for (int v = 0; v < KVMAX; ++v) pre[k][v] = *(const d2*)(row + loff[v]);
+                if (MASK) mk[k] = mbase[(int64_t)(dir ? T - 1 - s : s) * mpitch];
             }
         };
         // registers -> staged rows of chunk c (column K of every row is the zero that empty cells read)
-        auto stage = [&](const int c, const d2 (&pre)[C][KVMAX]) __attribute__((always_inline)) {
+        auto stage = [&](const int c, const d2 (&pre)[C][KVMAX], const unsigned long long (&mk)[CM]) __attribute__((always_inline)) {
             unsigned char* pb = smem + (size_t)(c & 1) * kBandPBytes;
             // whole pairs (16-byte writes; an odd K's last pair carries the unused pad column), piece by piece so
             // that the exec mask changes once per piece; then the zero column, which overwrites that pad
+            // (MASK: the columns start ZSH bytes into the row and the zero sits at offset 0)
 #pragma unroll
             for (int v = 0; v < KVMAX; ++v) {
                 if (128 * v + 2 * lane < K) {   // not a clamped duplicate
 #pragma unroll
-                    for (int k = 0; k < C; ++k) *(d2*)(pb + (size_t)k * kBandKP * 8 + loff[v]) = pre[k][v];
+                    for (int k = 0; k < C; ++k) *(d2*)(pb + (size_t)k * kBandKP * 8 + ZSH + loff[v]) = pre[k][v];
                 }
             }
             if (lane == 0) {
 #pragma unroll
-                for (int k = 0; k < C; ++k) *(double*)(pb + ((size_t)k * kBandKP + K) * 8) = 0.0;
+                for (int k = 0; k < C; ++k) *(double*)(pb + ((size_t)k * kBandKP + (MASK ? 0 : K)) * 8) = 0.0;
+            }
+            if (MASK) {
+                unsigned char* mb = smem + kBandMaskOff + (size_t)(c & 1) * kBandMBytes;
+#pragma unroll
+                for (int k = 0; k < C; ++k) *(unsigned long long*)(mb + (size_t)k * 512 + lane * 8) = mk[k];
             }
         };
         auto decide = [&](const int c) __attribute__((always_inline)) {
@@ -2266,10 +2309,10 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         // from the register set of its parity (loaded during iteration c-2), then issue(c+3) into the same set.
         // Even chunks use set A, odd chunks set B.
         if (nc > 0) {
-            issue(0, preA);
-            if (nc > 1) issue(1, preB);
-            stage(0, preA);
-            if (nc > 2) issue(2, preA);
+            issue(0, preA, mkA);
+            if (nc > 1) issue(1, preB, mkB);
+            stage(0, preA, mkA);
+            if (nc > 2) issue(2, preA, mkA);
         }
         unsigned long long t_bar = 0, t_stage = 0, t_issue = 0;
         for (int c = 0; c <= nc; c += 2) {
@@ -2278,10 +2321,10 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
             const unsigned long long tb = __builtin_amdgcn_s_memtime();
             t_bar += tb - ta;
             if (c + 1 < nc) {
-                stage(c + 1, preB);
+                stage(c + 1, preB, mkB);
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 const unsigned long long tc = __builtin_amdgcn_s_memtime();
-                if (c + 3 < nc) issue(c + 3, preB);
+                if (c + 3 < nc) issue(c + 3, preB, mkB);
                 const unsigned long long td = __builtin_amdgcn_s_memtime();
                 t_stage += tc - tb; t_issue += td - tc;
             }
@@ -2289,14 +2332,336 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
             if (c + 1 <= nc) {
                 __syncthreads();   // barrier c+1
                 if (c + 2 < nc) {
-                    stage(c + 2, preA);
-                    if (c + 4 < nc) issue(c + 4, preA);
+                    stage(c + 2, preA, mkA);
+                    if (c + 4 < nc) issue(c + 4, preA, mkA);
                 }
                 decide(c + 1);
             }
         }
         if ((p.ablate & 8) && blockIdx.x == 0 && lane == 0)
             printf("stager (even chunks): barrier-wait=%.0f stage=%.0f issue=%.0f cycles\n", 2.0 * t_bar / max(nc, 1), 2.0 * t_stage / max(nc, 1), 2.0 * t_issue / max(nc, 1));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// output_beam pruning on the banded path (k2.intersect_dense(..., output_beam), waterfall/graph.py:61-62,81; rule:
+// SURVEY 8(0), k2's own arithmetic parity unpinned).  Three launches in front of / around the probability-domain sweep:
+//   trop_band_kernel   tropical forward and backward sweep of the banded (or <= 64-state general) graph, the register
+//                      layout of sweep_band_kernel with fp32 add / max instead of fp64 FMAs and no rescaling; every
+//                      alpha^_t / beta^_t row leaves as fp32, best[u] = the tropical total
+//   band_mask_kernel   fully parallel: per (frame, lane) one 64-bit word per direction whose bit j*MM + m says whether the
+//                      lattice arc of the lane's cell (j, m) satisfies alpha^_t[src] + fl32(w + lp) + beta^_{t+1}[dst] >=
+//                      best - output_beam
+//   sweep_band_kernel<..., MASK>   the probability-domain sweep over the kept arcs only
+// post_small_kernel<., MASK> evaluates the same expression per arc from the same fp32 rows, so sweep and posteriors agree
+// on every arc.  max is exact and order-free, so the rows equal sweep_kernel<M_FB_MAX>'s bit for bit.
+// ------------------------------------------------------------------------------------------
+struct BandCell { int src, dst, oth, col; float w; bool on; };
+
+// Cell (j, m) of lane `lane` in direction dir, as sweep_band_kernel lays the arcs out: banded graphs j = r*(BW+1) + d (the
+// arc into position lane*R + r from d positions back; backward: the reversed order); GEN: j < WF_REG_DEG the lane's (=
+// state's) own arcs, j == WF_REG_DEG its share of the one high-degree state's arcs.  oth = the state the sweep reads.
+template <int R, int BW, int MM, bool GEN>
+__device__ __forceinline__ BandCell band_cell(const int32_t* blob, const int32_t* I, const int dir, const int lane, const int j, const int m) {
+    BandCell c{0, 0, 0, 0, 0.f, false};
+    const int Sn = I[WF_I_S] - 1;
+    if (GEN) {
+        constexpr int GD = WF_REG_DEG;
+        const int32_t* g_off = blob + I[dir ? WF_I_OUT_OFF : WF_I_IN_OFF];
+        const int32_t* g_oth = blob + I[dir ? WF_I_OUT_DST : WF_I_IN_SRC];
+        const int32_t* g_col = blob + I[dir ? WF_I_OUT_COL : WF_I_IN_COL];
+        const float* g_w = (const float*)(blob + I[dir ? WF_I_OUT_W : WF_I_IN_W]);
+        const int over = I[dir ? WF_I_NOVER_OUT : WF_I_NOVER_IN] > 0 ? I[dir ? WF_I_OVER_OUT : WF_I_OVER_IN] : -1;
+        int own = lane, arc = 0;
+        bool on = false;
+        if (j < GD) {
+            if (lane < Sn && lane != over) { arc = g_off[lane] + j; on = arc < g_off[lane + 1]; }
+        } else if (over >= 0) {
+            own = over;
+            arc = g_off[over] + lane;
+            on = arc < g_off[over + 1];
+        }
+        if (on) {
+            c.on = true; c.oth = g_oth[arc]; c.col = g_col[arc]; c.w = g_w[arc];
+            c.src = dir ? own : c.oth; c.dst = dir ? c.oth : own;
+        }
+        return c;
+    }
+    const int gbw = I[WF_I_BAND_BW], gm = I[WF_I_BAND_M];
+    const int r = j / (BW + 1), d = j % (BW + 1);
+    const int pp = lane * R + r;
+    if (pp < Sn && d <= gbw && m < gm && pp - d >= 0) {
+        const int32_t* order = blob + I[WF_I_BAND_ORDER];
+        const int32_t* ent = blob + I[dir ? WF_I_BANDB : WF_I_BANDF] + (((size_t)pp * (gbw + 1) + d) * gm + m) * 2;
+        const float w = __int_as_float(ent[1]);
+        if (w != -INFINITY) {   // (an unused slot of the cell)
+            const int own = order[dir ? Sn - 1 - pp : pp];
+            c.on = true; c.col = ent[0]; c.w = w; c.oth = order[dir ? Sn - 1 - (pp - d) : pp - d];
+            c.src = dir ? own : c.oth; c.dst = dir ? c.oth : own;
+        }
+    }
+    return c;
+}
+
+// wave_shr:1 of a float: lane i receives lane i-1's value, lane 0 keeps `fill`
+__device__ __forceinline__ float wave_shr1_f(float v, float fill) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float bperm_f(float v, int srclane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srclane << 2, __builtin_bit_cast(int, v)));
+}
+
+constexpr size_t kTropEBytes = (size_t)kBandC * kBandKP * 4;   // one chunk of staged emission rows (fp32)
+
+template <int R, int BW, int MM, bool GEN = false>
+__global__ void __launch_bounds__(128) trop_band_kernel(SweepArgs p) {
+    constexpr int GD = WF_REG_DEG;
+    constexpr int NQ = GEN ? GD + 1 : R * (BW + 1), C = kBandC;
+    extern __shared__ __align__(16) unsigned char smem[];   // staged emission rows [2][C][kBandKP] fp32; column K = -inf
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int fsa = uni((int)U[WF_U_FSA]), T = uni((int)U[WF_U_T]);
+    const int32_t* blob = p.blob;
+    const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
+    const int S = uni(I[WF_I_S]), A = uni(I[WF_I_A]), K = uni(I[WF_I_K]);
+    if (T < uni(I[WF_I_MINLEN])) {   // structurally infeasible: no rows, nothing is read from them either
+        if (dir == 0 && tid == 0) ((float*)p.tot)[u] = -INFINITY;
+        return;
+    }
+    const int Sn = S - 1;
+    const int nc = (T + C - 1) / C;
+    if (wave == 0) {
+        // =============================== chain wave ===============================
+        const int32_t* order = blob + uni(I[WF_I_BAND_ORDER]);
+        const float* fbm = (const float*)(blob + uni(I[WF_I_FINB_MAX]));
+        float* arena = (float*)(dir ? p.beta : p.alpha) + uni(U[dir ? WF_U_BETA : WF_U_ALPHA]);
+        float a[R];
+        int sidx[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int pp = lane * R + r;
+            int st = -1;
+            if (pp < Sn) st = GEN ? pp : order[dir ? Sn - 1 - pp : pp];
+            a[r] = st < 0 ? -INFINITY : (dir ? fbm[st] : (st == 0 ? 0.f : -INFINITY));
+            sidx[r] = st < 0 ? S - 1 : st;
+            arena[(int64_t)(dir ? T : 0) * S + sidx[r]] = a[r];   // alpha^_0 / beta^_T
+        }
+        unsigned coff[NQ][MM];
+        float cw[NQ][MM];
+        int gsrc[NQ];
+        int over = -1;
+        if (GEN && uni(I[dir ? WF_I_NOVER_OUT : WF_I_NOVER_IN]) > 0) over = uni(I[dir ? WF_I_OVER_OUT : WF_I_OVER_IN]);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const BandCell c = band_cell<R, BW, MM, GEN>(blob, I, dir, lane, j, m);
+                coff[j][m] = (unsigned)(c.on ? c.col : K) * 4u;   // an empty cell reads column K = -inf
+                cw[j][m] = c.on ? c.w : 0.f;
+                if (m == 0) gsrc[j] = c.on ? c.oth : 0;
+            }
+        }
+        float* srow = arena + (int64_t)(dir ? (T - 1) : 1) * S;
+        const int64_t sstep = dir ? -(int64_t)S : (int64_t)S;
+        // x[j][m] = fl32(w + lp) of cell (j, m) in the frame at row k of the staged chunk
+        auto load_x = [&](const unsigned char* pb, const int k, float (&x)[NQ][MM]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                for (int m = 0; m < MM; ++m) x[j][m] = cw[j][m] + *(const float*)(pb + (size_t)k * kBandKP * 4 + coff[j][m]);
+        };
+        auto step = [&](const float (&x)[NQ][MM]) __attribute__((always_inline)) {
+            if (GEN) {
+                float v = bperm_f(a[0], gsrc[0]) + x[0][0];
+#pragma unroll
+                for (int j = 1; j < GD; ++j) v = fmaxf(v, bperm_f(a[0], gsrc[j]) + x[j][0]);
+                const float hub = wave_max(bperm_f(a[0], gsrc[GD]) + x[GD][0]);
+                if (lane == over) v = hub;
+                a[0] = v;
+                srow[sidx[0]] = v;
+                srow += sstep;
+                return;
+            }
+            float nb[BW];
+#pragma unroll
+            for (int j = 0; j < BW; ++j) nb[j] = wave_shr1_f(a[R - 1 - j], -INFINITY);
+            float an[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float v = -INFINITY;
+#pragma unroll
+                for (int d = 0; d <= BW; ++d) {
+                    const float sv = (r - d >= 0) ? a[r - d >= 0 ? r - d : 0] : nb[d - r - 1 >= 0 ? d - r - 1 : 0];
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) v = fmaxf(v, sv + x[r * (BW + 1) + d][m]);
+                }
+                an[r] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                a[r] = an[r];
+                srow[sidx[r]] = an[r];
+            }
+            srow += sstep;
+        };
+        const int nfull = T / C;
+        for (int c = 0; c < nfull; ++c) {
+            __syncthreads();   // the rows of chunk c are staged
+            const unsigned char* pb = smem + (size_t)(c & 1) * kTropEBytes;
+            float x0[NQ][MM], x1[NQ][MM];
+            load_x(pb, 0, x0);
+#pragma unroll
+            for (int k = 0; k < C; k += 2) {
+                load_x(pb, k + 1, x1);
+                step(x0);
+                if (k + 2 < C) load_x(pb, k + 2, x0);
+                step(x1);
+            }
+        }
+        if (nfull < nc) {
+            __syncthreads();
+            const unsigned char* pb = smem + (size_t)(nfull & 1) * kTropEBytes;
+            const int nk = T - nfull * C;
+            for (int k = 0; k < nk; ++k) {
+                float x0[NQ][MM];
+                load_x(pb + (size_t)k * kBandKP * 4, 0, x0);
+                step(x0);
+            }
+        }
+        __syncthreads();
+        if (dir == 0) {   // best = max over the final arcs of alpha^_T[src] + w
+            float part = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int pp = lane * R + r;
+                if (pp < Sn) part = fmaxf(part, a[r] + fbm[GEN ? pp : order[pp]]);
+            }
+            const float best = wave_max(part);
+            if (lane == 0) ((float*)p.tot)[u] = best;
+        }
+    } else {
+        // =============================== stager wave ===============================
+        const bool has_e = A > 0 && T > 0;
+        const int direct = uni(I[WF_I_DIRECT]);
+        const float* ebase = direct ? p.lp + uni(U[WF_U_SEQ]) * p.strideB + uni(U[WF_U_START]) * p.strideT : p.E + uni(U[WF_U_E]);
+        int64_t epitch = direct ? p.strideT : (int64_t)K;
+        if (!has_e) { ebase = (const float*)U; epitch = 0; }   // every load stays unconditional (values unused)
+        const int last_step = max(T - 1, 0);
+        constexpr int KV = kBandKP / 64;
+        int lcol[KV];
+#pragma unroll
+        for (int v = 0; v < KV; ++v) lcol[v] = has_e ? min(64 * v + lane, K - 1) : 0;
+        float preA[C][KV], preB[C][KV];
+        auto issue = [&](const int c, float (&pre)[C][KV]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const int s = min(c * C + k, last_step);
+                const float* row = ebase + (int64_t)(dir ? T - 1 - s : s) * epitch;
+#pragma unroll
+                for (int v = 0; v < KV; ++v) pre[k][v] = row[lcol[v]];
+            }
+        };
+        auto stage = [&](const int c, const float (&pre)[C][KV]) __attribute__((always_inline)) {
+            unsigned char* pb = smem + (size_t)(c & 1) * kTropEBytes;
+#pragma unroll
+            for (int v = 0; v < KV; ++v) {
+                if (64 * v + lane < K) {
+#pragma unroll
+                    for (int k = 0; k < C; ++k) *(float*)(pb + ((size_t)k * kBandKP + 64 * v + lane) * 4) = pre[k][v];
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < C; ++k) *(float*)(pb + ((size_t)k * kBandKP + K) * 4) = -INFINITY;
+            }
+        };
+        // the schedule of sweep_band_kernel's stager: stage(c+1) between barriers c and c+1 from the register set of its
+        // parity (loaded two chunks earlier), then issue(c+3) into the same set
+        if (nc > 0) {
+            issue(0, preA);
+            if (nc > 1) issue(1, preB);
+            stage(0, preA);
+            if (nc > 2) issue(2, preA);
+        }
+        for (int c = 0; c <= nc; c += 2) {
+            __syncthreads();   // barrier c (c even)
+            if (c + 1 < nc) {
+                stage(c + 1, preB);
+                if (c + 3 < nc) issue(c + 3, preB);
+            }
+            if (c + 1 <= nc) {
+                __syncthreads();   // barrier c+1
+                if (c + 2 < nc) {
+                    stage(c + 2, preA);
+                    if (c + 4 < nc) issue(c + 4, preA);
+                }
+            }
+        }
+    }
+}
+
+struct BandMaskArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const float* lp;
+    int64_t strideB, strideT;
+    const float* E;
+    const float* mA;     // tropical alpha^ rows, fp32, element offsets of the alpha arena
+    const float* mB;
+    const float* best;   // [B]
+    float beam;
+    float* thr;          // [B] out: best - beam (post kernels, rescue)
+    unsigned long long* mask;   // [2][rows][64]
+    int64_t rows;
+};
+
+constexpr int kMaskFR = 4;   // frames per wavefront
+
+template <int R, int BW, int MM, bool GEN = false>
+__global__ void __launch_bounds__(64) band_mask_kernel(BandMaskArgs p) {
+    constexpr int NQ = GEN ? WF_REG_DEG + 1 : R * (BW + 1);
+    const int lane = threadIdx.x;
+    const int t0 = blockIdx.x * kMaskFR, u = blockIdx.y;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int T = (int)U[WF_U_T];
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const float thr = p.best[u] - p.beam;
+    if (t0 == 0 && lane == 0) p.thr[u] = thr;
+    if (t0 >= T || T < I[WF_I_MINLEN]) return;
+    const int S = I[WF_I_S], K = I[WF_I_K], direct = I[WF_I_DIRECT];
+    const float* ebase = direct ? p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT : p.E + U[WF_U_E];
+    const int64_t epitch = direct ? p.strideT : (int64_t)K;
+    const float* abase = p.mA + U[WF_U_ALPHA];
+    const float* bbase = p.mB + U[WF_U_BETA];
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        int src[NQ][MM], dst[NQ][MM], col[NQ][MM];
+        float w[NQ][MM];
+        unsigned long long on = 0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const BandCell c = band_cell<R, BW, MM, GEN>(p.blob, I, dir, lane, j, m);
+                src[j][m] = c.src; dst[j][m] = c.dst; col[j][m] = c.col; w[j][m] = c.w;   // an empty cell: state 0, column 0
+                if (c.on) on |= 1ull << (j * MM + m);
+            }
+        unsigned long long* out = p.mask + ((int64_t)dir * p.rows + U[WF_U_ROW0]) * 64 + lane;
+        for (int t = t0; t < min(t0 + kMaskFR, T); ++t) {
+            const float* arow = abase + (int64_t)t * S;
+            const float* brow = bbase + (int64_t)(t + 1) * S;
+            const float* erow = ebase + (int64_t)t * epitch;
+            unsigned long long keep = 0;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    const float x = w[j][m] + erow[col[j][m]];
+                    if (arow[src[j][m]] + x + brow[dst[j][m]] >= thr) keep |= 1ull << (j * MM + m);
+                }
+            out[(int64_t)t * 64] = keep & on;
+        }
     }
 }
 
@@ -3492,7 +3857,10 @@ __global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
 constexpr int kPostFR = 4;
 constexpr int kPostHeavy = 48;   // arcs per column from which the wave sums the column cooperatively (a lane sums a shorter column alone: all columns in parallel, ~30 cycles an arc, against ~250 cycles per column of the wave-wide path)
 
-template <int PSS>
+// MASK (output_beam pruning): the tropical rows alpha^_t / beta^_{t+1} and the raw emissions are staged too, and an arc
+// whose alpha^_t[src] + fl32(w + lp) + beta^_{t+1}[dst] falls below the utterance's threshold contributes nothing -- the
+// expression, operand order and fp32 rows of band_mask_kernel and of the masked sweep_kernel.
+template <int PSS, bool MASK = false>
 __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     constexpr int PSA = 2 * PSS;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -3500,6 +3868,9 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
     float* lb = la + p.smax;
     float* le = lb + p.smax;
     float* lpost = le + p.ecap;
+    float* lma = lpost + p.acap;            // MASK: alpha^_t[s], beta^_{t+1}[s], raw emissions
+    float* lmb = lma + p.smax;
+    float* ler = lmb + p.smax;
     const int lane = threadIdx.x;
     const int f0 = blockIdx.x * kPostFR, q = blockIdx.y;
     const int u = p.seq2utt[q];
@@ -3545,12 +3916,16 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
 
     // ---- frame-independent: this lane's arcs and columns (indices clamped so that no load is conditional)
     int asrc[PSA], adst[PSA], acol[PSA];
-    float aw[PSA];
+    float aw[PSA], awr[MASK ? PSA : 1];
 #pragma unroll
     for (int i = 0; i < PSA; ++i) {
         const int a = min(lane + i * 64, A - 1);
         asrc[i] = lsrc[a]; adst[i] = ldst[a]; acol[i] = lcol[a]; aw[i] = lw[a] * kLog2e;
+        if (MASK) awr[i] = lw[a];
     }
+    const float* mabase = MASK ? p.mA + U[WF_U_ALPHA] : nullptr;
+    const float* mbbase = MASK ? p.mB + U[WF_U_BETA] : nullptr;
+    const float mthr = MASK ? p.thr[u] : 0.f;
     int k0[PSS], k1[PSS], kend[PSS], klab[PSS];
     unsigned long long heavy[PSS];   // wave mask of the columns of slot i that are summed cooperatively
 #pragma unroll
@@ -3564,7 +3939,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
 
     // ---- row prefetch registers (frame t): alpha_t, beta_{t+1}, emissions, offsets
     double av[PSS], bv[PSS], c_t, ga, gb;
-    float ev[PSS];
+    float ev[PSS], mav[MASK ? PSS : 1], mbv[MASK ? PSS : 1];
     auto fetch = [&](const int t) __attribute__((always_inline)) {
         const double* arow = abase + (int64_t)t * S;
         const double* brow = bbase + (int64_t)(t + 1) * S;
@@ -3575,6 +3950,7 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
             av[i] = arow[s];
             bv[i] = brow[s];
             ev[i] = erow[min(lane + i * 64, K - 1)];
+            if (MASK) { mav[i] = mabase[(int64_t)t * S + s]; mbv[i] = mbbase[(int64_t)(t + 1) * S + s]; }
         }
         c_t = lin ? cmax[t] : 0.0;
         ga = aoffs[lin ? lin_shift_index(t - 1, p.lin, p.lag) : 0];
@@ -3610,8 +3986,9 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
             if (s < S) {
                 la[s] = lin ? lin_log2f(av[i], a_ref) : (float)(av[i] - a_ref) * xs;
                 lb[s] = lin ? lin_log2f(bv[i], b_ref) : (float)(bv[i] - b_ref) * xs;
+                if (MASK) { lma[s] = mav[i]; lmb[s] = mbv[i]; }
             }
-            if (s < K) le[s] = ev[i] * kLog2e;
+            if (s < K) { le[s] = ev[i] * kLog2e; if (MASK) ler[s] = ev[i]; }
         }
         if (t + 1 < t1) fetch(t + 1);   // next frame's loads fly while this frame is reduced
         // One wavefront: its LDS operations execute in order, so no s_barrier is needed -- and __syncthreads() would
@@ -3623,7 +4000,8 @@ __global__ void __launch_bounds__(64) post_small_kernel(PostArgs p) {
         for (int i = 0; i < PSA; ++i) {
             const int a = lane + i * 64;
             if (a < A) {
-                const float pv = __builtin_amdgcn_exp2f(la[asrc[i]] + lb[adst[i]] + (aw[i] + le[acol[i]]));
+                float pv = __builtin_amdgcn_exp2f(la[asrc[i]] + lb[adst[i]] + (aw[i] + le[acol[i]]));
+                if (MASK && !(lma[asrc[i]] + (awr[i] + ler[acol[i]]) + lmb[adst[i]] >= mthr)) pv = 0.f;   // pruned lattice arc
                 lpost[a] = pv;
                 chk += pv;
             }
@@ -3685,6 +4063,9 @@ struct RescueArgs {
     float* tot;
     double* totd;
     float* grad;
+    const float* mA;   // output_beam pruning (null: none): tropical rows and thresholds; only kept lattice arcs count
+    const float* mB;
+    const float* thr;
 };
 
 __device__ __forceinline__ double lse2_d(double a, double b) {   // log(exp(a) + exp(b)), -inf safe
@@ -3705,6 +4086,12 @@ __global__ void __launch_bounds__(256) rescue_kernel(RescueArgs p) {
     const int64_t epitch = direct ? p.strideT : K;
     double* A_ = p.alpha + U[WF_U_ALPHA];
     double* B_ = p.beta + U[WF_U_BETA];
+    const bool masked = p.mA != nullptr;
+    const float* MA_ = masked ? p.mA + U[WF_U_ALPHA] : nullptr;
+    const float* MB_ = masked ? p.mB + U[WF_U_BETA] : nullptr;
+    const float mthr = masked ? p.thr[u] : 0.f;
+    // kept(t, src, x, dst): the lattice arc survives the beam (the expression of the masked sweeps / post kernels)
+    auto kept = [&](int t, int s_, float x, int d_) { return !masked || MA_[(int64_t)t * S + s_] + x + MB_[(int64_t)(t + 1) * S + d_] >= mthr; };
     // ---- forward
     {
         const int32_t* off = p.blob + I[WF_I_IN_OFF];
@@ -3719,10 +4106,12 @@ __global__ void __launch_bounds__(256) rescue_kernel(RescueArgs p) {
             const float* erow = ebase + (int64_t)t * epitch;
             for (int s = tid; s < S; s += nt) {
                 double m = (double)-INFINITY;
-                for (int a = off[s]; a < off[s + 1]; ++a) m = fmax(m, cur[src[a]] + (double)(w[a] + erow[col[a]]));
+                for (int a = off[s]; a < off[s + 1]; ++a)
+                    if (kept(t, src[a], w[a] + erow[col[a]], s)) m = fmax(m, cur[src[a]] + (double)(w[a] + erow[col[a]]));
                 double sum = 0.0;
                 if (m > (double)-INFINITY)
-                    for (int a = off[s]; a < off[s + 1]; ++a) sum += exp(cur[src[a]] + (double)(w[a] + erow[col[a]]) - m);
+                    for (int a = off[s]; a < off[s + 1]; ++a)
+                        if (kept(t, src[a], w[a] + erow[col[a]], s)) sum += exp(cur[src[a]] + (double)(w[a] + erow[col[a]]) - m);
                 nxt[s] = m > (double)-INFINITY ? m + log(sum) : m;
             }
             __syncthreads();
@@ -3754,10 +4143,12 @@ __global__ void __launch_bounds__(256) rescue_kernel(RescueArgs p) {
             const float* erow = ebase + (int64_t)t * epitch;
             for (int s = tid; s < S; s += nt) {
                 double m = (double)-INFINITY;
-                for (int a = off[s]; a < off[s + 1]; ++a) m = fmax(m, nxt[dst[a]] + (double)(w[a] + erow[col[a]]));
+                for (int a = off[s]; a < off[s + 1]; ++a)
+                    if (kept(t, s, w[a] + erow[col[a]], dst[a])) m = fmax(m, nxt[dst[a]] + (double)(w[a] + erow[col[a]]));
                 double sum = 0.0;
                 if (m > (double)-INFINITY)
-                    for (int a = off[s]; a < off[s + 1]; ++a) sum += exp(nxt[dst[a]] + (double)(w[a] + erow[col[a]]) - m);
+                    for (int a = off[s]; a < off[s + 1]; ++a)
+                        if (kept(t, s, w[a] + erow[col[a]], dst[a])) sum += exp(nxt[dst[a]] + (double)(w[a] + erow[col[a]]) - m);
                 cur[s] = m > (double)-INFINITY ? m + log(sum) : m;
             }
             __syncthreads();
@@ -3778,9 +4169,11 @@ __global__ void __launch_bounds__(256) rescue_kernel(RescueArgs p) {
         if (tot > (double)-INFINITY) {
             const double* ar = A_ + (int64_t)t * S;
             const double* br = B_ + (int64_t)(t + 1) * S;
-            const double e = (double)ebase[(int64_t)t * epitch + k];
+            const float ef = ebase[(int64_t)t * epitch + k];
+            const double e = (double)ef;
             double acc = 0.0;
-            for (int a = loff[k]; a < loff[k + 1]; ++a) acc += exp(ar[lsrc[a]] + ((double)lw[a] + e) + br[ldst[a]] - tot);
+            for (int a = loff[k]; a < loff[k + 1]; ++a)
+                if (kept(t, lsrc[a], lw[a] + ef, ldst[a])) acc += exp(ar[lsrc[a]] + ((double)lw[a] + e) + br[ldst[a]] - tot);
             val = gs * (float)acc;
         }
         p.grad[(int64_t)seq * p.strideB + (int64_t)(start + t) * p.strideT + (direct ? k : labels[k])] = val;
@@ -4268,7 +4661,8 @@ struct Plan {
     int64_t n_E = 0, n_ab = 0, n_P = 0, n_rows = 0;
     bool lin = false;   // forward-backward by a linear-domain sweep (decided in make_plan)
     bool pruned = false;   // output_beam pruning: tropical rows + thresholds live in the workspace
-    size_t off_mA = 0, off_mB = 0, off_best = 0, off_thr = 0;
+    bool pruned_fast = false;   // ... on the banded probability-domain path (trop_band_kernel + band_mask_kernel + MASK sweep)
+    size_t off_mA = 0, off_mB = 0, off_best = 0, off_thr = 0, off_bmask = 0;
     bool big = false;       // graphs too large for the LDS sweeps: one launch per frame
     bool shared = false;    // ... and the whole batch uses one graph (forward-only calls): kNB utterances per lane
     bool one_fsa = true;
@@ -4292,6 +4686,18 @@ int check_blob(const void* graph_host) {
     return WF_OK;
 }
 
+// Every segment inside the log_probs box [num_seqs][Tmax][V]: the only guard between a bad supervision_segments row
+// and an out-of-bounds device read, so every compute entry point runs it (the Python drop-in asserts the same).
+int check_segments(const char* who, const int32_t* seg, int B, int num_seqs, int Tmax) {
+    if (!seg || B < 1) return wf_fail(WF_EINVAL, "%s: bad B/seg", who);
+    for (int i = 0; i < B; ++i) {
+        const int64_t b = seg[3 * i], st = seg[3 * i + 1], T = seg[3 * i + 2];
+        if (b < 0 || b >= num_seqs || st < 0 || T < 0 || st + T > Tmax)
+            return wf_fail(WF_ERANGE, "%s: segment %d = (%d,%d,%d) outside log_probs [%d][%d][.]", who, i, (int)b, (int)st, (int)T, num_seqs, Tmax);
+    }
+    return WF_OK;
+}
+
 // mode: 0 = forward-backward (alpha+beta arenas), 1 = tot only, 2 = viterbi (bp arena)
 struct RegCfg {
     bool ok = false;
@@ -4305,7 +4711,7 @@ constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where not
 // when a test calls wf_debug_reload_env() after changing them -- no getenv on the production path.
 struct Hooks {
     int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
-        zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache,
+        zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache, no_pruned_fast,
         post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern, no_tab_kernarg, no_hub_split, hub_force_split;
 };
 Hooks g_hooks;
@@ -4331,6 +4737,7 @@ void load_hooks() {
     h.no_hub = env_int("WF_NO_HUB_SWEEP", 0); h.no_hub_pattern = env_int("WF_NO_HUB_PATTERN", 0);
     h.no_tab_kernarg = env_int("WF_NO_TAB_KERNARG", 0); h.no_hub_split = env_int("WF_NO_HUB_SPLIT", 0);
     h.hub_force_split = env_int("WF_HUB_FORCE_SPLIT", 0);
+    h.no_pruned_fast = env_int("WF_NO_PRUNED_FAST", 0);
     g_hooks = h;
     g_hooks_loaded = true;
 }
@@ -4443,7 +4850,12 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     if (mode == 0) {
         P->pruned = pruned;
         const bool hub_ok = hub_config(*P);
-        P->lin = acc_bytes == 8 && !dbl_exact && !pruned && !P->big && (band_config(*P).ok || lin_config(*P).ok || hub_ok || linbig_config(*P));
+        // output_beam pruning stays on the probability-domain path where the banded wave sweep applies (every numerator,
+        // the small denominators); elsewhere: tropical + masked log-semiring sweeps (sweep_kernel / big_step_kernel)
+        P->pruned_fast = pruned && acc_bytes == 8 && !dbl_exact && !P->big && band_config(*P).ok && post_small_fits(*P) &&
+                         P->kmax <= kBandMaskKMax && !hk().no_pruned_fast;
+        P->lin = acc_bytes == 8 && !dbl_exact && !P->big &&
+                 (pruned ? P->pruned_fast : (band_config(*P).ok || lin_config(*P).ok || hub_ok || linbig_config(*P)));
         P->hub = P->lin && !band_config(*P).ok && !lin_config(*P).ok && hub_ok;
         P->linbig = P->lin && !band_config(*P).ok && !lin_config(*P).ok && !P->hub;
         if (P->hub) nP = 0;   // no probability arena: the sweep reads log_probs itself
@@ -4471,6 +4883,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
             P->off_mB = o; o = align_up(o + sizeof(float) * (size_t)nab, 256);
             P->off_best = o; o = align_up(o + sizeof(float) * B, 256);
             P->off_thr = o; o = align_up(o + sizeof(float) * B, 256);
+            if (P->pruned_fast) { P->off_bmask = o; o = align_up(o + 2 * sizeof(unsigned long long) * 64 * (size_t)std::max<int64_t>(row0, 1), 256); }
         }
         P->off_aoff = o; o = align_up(o + sizeof(double) * (size_t)(row0 + B), 256);
         P->off_boff = o; o = align_up(o + sizeof(double) * (size_t)(row0 + B), 256);
@@ -4516,6 +4929,7 @@ constexpr size_t kScratchBytes = (size_t)WF_STATIC_SCRATCH_BYTES;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 16;
 void* g_scratch_ptr[kMaxDevices] = {};
+std::once_flag g_scratch_once[kMaxDevices];   // host threads may set up their contexts on one device concurrently
 
 // Per host thread and device: side streams for work that can overlap the latency-bound sweeps, their events, and a
 // ring of pinned staging slots for the per-call tables (so that the host-to-device copy of a call is a true
@@ -4565,11 +4979,13 @@ int side_get(Side** out, bool create = true) {
         for (auto& e : s.ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         int rc = ring_alloc(s, kRingSlotInit);
         if (rc) return rc;
-        if (!g_scratch_ptr[dev]) {
+        hipError_t sym_err = hipSuccess;
+        std::call_once(g_scratch_once[dev], [&]() {
             void* ptr = nullptr;
-            HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));   // this device's copy of the array
-            g_scratch_ptr[dev] = ptr;
-        }
+            sym_err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));   // this device's copy of the array
+            g_scratch_ptr[dev] = sym_err == hipSuccess ? ptr : nullptr;
+        });
+        if (sym_err != hipSuccess || !g_scratch_ptr[dev]) return wf_fail(WF_EHIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(sym_err));
         s.scratch_ptr = g_scratch_ptr[dev];
     }
     *out = &s;
@@ -4900,9 +5316,9 @@ BandSel band_config(const Plan& P) {
     return b;
 }
 
-template <int R, int BW, int MM, bool WE, bool GEN = false>
+template <int R, int BW, int MM, bool WE, bool GEN = false, bool MASK = false>
 int launch_band_one(SweepArgs a, int B, hipStream_t st, int nfill) {
-    auto k = sweep_band_kernel<R, BW, MM, WE, GEN>;
+    auto k = sweep_band_kernel<R, BW, MM, WE, GEN, MASK>;
     { int rc_ = ensure_lds((const void*)k, kBandLds); if (rc_) return rc_; }
     a.nsweep = B * 2;
     hipLaunchKernelGGL(k, dim3(B * 2 + nfill), dim3(128), kBandLds, st, a);
@@ -4911,9 +5327,23 @@ int launch_band_one(SweepArgs a, int B, hipStream_t st, int nfill) {
 }
 
 // nfill > 0: that many extra workgroups zero-fill a.zp / a.ztail (see SweepArgs)
-int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st, int nfill = 0) {
+// masked: output_beam pruning, a.bmask holds the keep-mask words (launch_trop_band ran before)
+int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st, int nfill = 0, bool masked = false) {
     const int prof = hk().sweep_profile;
     a.ablate = prof;
+    if (masked) {
+        if (b.gen) return b.we ? launch_band_one<1, 1, 1, true, true, true>(a, B, st, nfill) : launch_band_one<1, 1, 1, false, true, true>(a, B, st, nfill);
+#define WF_BAND_CASE(RR, WW)                                                                     \
+    if (b.BW == WW && b.R == RR)                                                                  \
+        return b.we ? launch_band_one<RR, WW, 1, true, false, true>(a, B, st, nfill)                                   \
+                    : (b.M == 1 ? launch_band_one<RR, WW, 1, false, false, true>(a, B, st, nfill) : launch_band_one<RR, WW, 2, false, false, true>(a, B, st, nfill))
+        WF_BAND_CASE(2, 2);
+        WF_BAND_CASE(3, 2);
+        WF_BAND_CASE(4, 2);
+        WF_BAND_CASE(4, 4);
+#undef WF_BAND_CASE
+        return wf_fail(WF_EUNSUPPORTED, "internal: no banded sweep for R=%d BW=%d", b.R, b.BW);
+    }
     if (b.gen) return b.we ? launch_band_one<1, 1, 1, true, true>(a, B, st, nfill) : launch_band_one<1, 1, 1, false, true>(a, B, st, nfill);
 #define WF_BAND_CASE(RR, WW)                                                                     \
     if (b.BW == WW && b.R == RR)                                                                  \
@@ -4927,15 +5357,49 @@ int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st, int 
     return wf_fail(WF_EUNSUPPORTED, "internal: no banded sweep for R=%d BW=%d", b.R, b.BW);
 }
 
+// output_beam pruning on the banded path, first two launches: the tropical forward-backward rows (a.alpha / a.beta / a.tot
+// = the fp32 arenas and best[]), then the keep-mask words
+template <int R, int BW, int MM, bool GEN = false>
+int launch_trop_one(const SweepArgs& a, const BandMaskArgs& m, int B, int Tlong, hipStream_t st) {
+    auto k = trop_band_kernel<R, BW, MM, GEN>;
+    { int rc_ = ensure_lds((const void*)k, kBandLds); if (rc_) return rc_; }
+    hipLaunchKernelGGL(k, dim3(B * 2), dim3(128), kBandLds, st, a);
+    hipLaunchKernelGGL((band_mask_kernel<R, BW, MM, GEN>), dim3((std::max(Tlong, 1) + kMaskFR - 1) / kMaskFR, B), dim3(64), 0, st, m);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+int launch_trop_band(const BandSel& b, const SweepArgs& a, const BandMaskArgs& m, int B, int Tlong, hipStream_t st) {
+    if (b.gen) return launch_trop_one<1, 1, 1, true>(a, m, B, Tlong, st);
+#define WF_TROP_CASE(RR, WW) \
+    if (b.BW == WW && b.R == RR) return b.M == 1 ? launch_trop_one<RR, WW, 1>(a, m, B, Tlong, st) : launch_trop_one<RR, WW, 2>(a, m, B, Tlong, st)
+    WF_TROP_CASE(2, 2);
+    WF_TROP_CASE(3, 2);
+    WF_TROP_CASE(4, 2);
+    WF_TROP_CASE(4, 4);
+#undef WF_TROP_CASE
+    return wf_fail(WF_EUNSUPPORTED, "internal: no banded tropical sweep for R=%d BW=%d", b.R, b.BW);
+}
+
 // wf_init: the dynamic-LDS attribute of every banded instantiation, so that a later launch finds it set
 int ensure_band_lds() {
     int rc = 0;
+#define WF_TROP_ATTR(...) if ((rc = ensure_lds((const void*)trop_band_kernel<__VA_ARGS__>, kBandLds))) return rc
+    WF_TROP_ATTR(1, 1, 1, true);
+    WF_TROP_ATTR(2, 2, 1); WF_TROP_ATTR(2, 2, 2); WF_TROP_ATTR(3, 2, 1); WF_TROP_ATTR(3, 2, 2);
+    WF_TROP_ATTR(4, 2, 1); WF_TROP_ATTR(4, 2, 2); WF_TROP_ATTR(4, 4, 1); WF_TROP_ATTR(4, 4, 2);
+#undef WF_TROP_ATTR
 #define WF_BAND_ATTR(...) if ((rc = ensure_lds((const void*)sweep_band_kernel<__VA_ARGS__>, kBandLds))) return rc
     WF_BAND_ATTR(1, 1, 1, true, true); WF_BAND_ATTR(1, 1, 1, false, true);
     WF_BAND_ATTR(2, 2, 1, true); WF_BAND_ATTR(2, 2, 1, false); WF_BAND_ATTR(2, 2, 2, false);
     WF_BAND_ATTR(3, 2, 1, true); WF_BAND_ATTR(3, 2, 1, false); WF_BAND_ATTR(3, 2, 2, false);
     WF_BAND_ATTR(4, 2, 1, true); WF_BAND_ATTR(4, 2, 1, false); WF_BAND_ATTR(4, 2, 2, false);
     WF_BAND_ATTR(4, 4, 1, true); WF_BAND_ATTR(4, 4, 1, false); WF_BAND_ATTR(4, 4, 2, false);
+    WF_BAND_ATTR(1, 1, 1, true, true, true); WF_BAND_ATTR(1, 1, 1, false, true, true);
+    WF_BAND_ATTR(2, 2, 1, true, false, true); WF_BAND_ATTR(2, 2, 1, false, false, true); WF_BAND_ATTR(2, 2, 2, false, false, true);
+    WF_BAND_ATTR(3, 2, 1, true, false, true); WF_BAND_ATTR(3, 2, 1, false, false, true); WF_BAND_ATTR(3, 2, 2, false, false, true);
+    WF_BAND_ATTR(4, 2, 1, true, false, true); WF_BAND_ATTR(4, 2, 1, false, false, true); WF_BAND_ATTR(4, 2, 2, false, false, true);
+    WF_BAND_ATTR(4, 4, 1, true, false, true); WF_BAND_ATTR(4, 4, 1, false, false, true); WF_BAND_ATTR(4, 4, 2, false, false, true);
 #undef WF_BAND_ATTR
     return WF_OK;
 }
@@ -5227,6 +5691,17 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
         size_t lds2 = (2 * (size_t)q.smax + q.ecap + q.acap) * 4;
         const int need = std::max(std::max((P.smax + 63) / 64, (P.kmax + 63) / 64), (P.amax + 127) / 128);
         const dim3 grid((Tmax + kPostFR - 1) / kPostFR, num_seqs);
+        if (P.pruned) {   // masked posteriors: the tropical rows and raw emissions are staged as well
+            lds2 += (2 * (size_t)q.smax + q.ecap) * 4;
+            if (need <= 2) hipLaunchKernelGGL((post_small_kernel<2, true>), grid, dim3(64), lds2, st, q);
+            else if (need <= 3) hipLaunchKernelGGL((post_small_kernel<3, true>), grid, dim3(64), lds2, st, q);
+            else if (need <= 4) hipLaunchKernelGGL((post_small_kernel<4, true>), grid, dim3(64), lds2, st, q);
+            else if (need <= 5) hipLaunchKernelGGL((post_small_kernel<5, true>), grid, dim3(64), lds2, st, q);
+            else if (need <= 6) hipLaunchKernelGGL((post_small_kernel<6, true>), grid, dim3(64), lds2, st, q);
+            else hipLaunchKernelGGL((post_small_kernel<8, true>), grid, dim3(64), lds2, st, q);
+            HIP_TRY(hipGetLastError());
+            return WF_OK;
+        }
         if (need <= 2) hipLaunchKernelGGL(post_small_kernel<2>, grid, dim3(64), lds2, st, q);
         else if (need <= 3) hipLaunchKernelGGL(post_small_kernel<3>, grid, dim3(64), lds2, st, q);   // cfg3: S ~ 130, A ~ 323 (the kernel is instruction-bound)
         else if (need <= 4) hipLaunchKernelGGL(post_small_kernel<4>, grid, dim3(64), lds2, st, q);
@@ -5279,8 +5754,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     bool fwd_via_fb = false;
     int rc = plan_fb(graph_host, utt2fsa, seg, B, V, num_seqs, need_ab || pruned, dbl, pruned, &P, &fwd_via_fb);
     if (rc) return rc;
-    for (int i = 0; i < B; ++i)
-        if (seg[3 * i + 1] + seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d exceeds Tmax=%d", i, Tmax);
+    if ((rc = check_segments("wf_fb_logsum", seg, B, num_seqs, Tmax))) return rc;
     Side* side = nullptr;
     if (use_scratch) {
         if ((rc = side_get(&side, false))) return rc;
@@ -5294,7 +5768,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
     std::vector<int32_t> seq2utt;
     if (need_ab || pruned) { rc = build_seq2utt(seg, B, num_seqs, &seq2utt); if (rc) return rc; }
-    const bool tab = tab_in_kernarg(P, num_seqs, need_ab || pruned) && !pruned;
+    const bool tab = tab_in_kernarg(P, num_seqs, need_ab || pruned) && (!pruned || P.pruned_fast);
     if (!tab) {
         rc = upload_tables(P, ws, (need_ab || pruned) ? seq2utt.data() : nullptr, num_seqs, st, !use_scratch);
         if (rc) return rc;
@@ -5389,13 +5863,27 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
             a.zp = (float4*)grad; a.zn4 = n / 4; a.ztail = grad + (n / 4) * 4; a.zntail = (int)(n - (n / 4) * 4);
             nfill = nfill_sweep;
         }
-        rc = P.hub ? launch_sweep_hub(P, a, B, st) : bs.ok ? launch_sweep_band(bs, a, B, st, nfill) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
+        if (P.pruned_fast) {
+            // output_beam: tropical rows + best, then the keep-mask words the MASK sweep stages (the banded form only)
+            SweepArgs ta = a;
+            ta.alpha = ws + P.off_mA; ta.beta = ws + P.off_mB; ta.tot = ws + P.off_best; ta.totd = nullptr;
+            BandMaskArgs bm{a.blob, a.utt, log_probs, strideB, strideT, a.E, (const float*)(ws + P.off_mA), (const float*)(ws + P.off_mB),
+                            (const float*)(ws + P.off_best), output_beam, (float*)(ws + P.off_thr),
+                            (unsigned long long*)(ws + P.off_bmask), P.n_rows};
+            if ((rc = launch_trop_band(bs, ta, bm, B, P.Tlong, st))) return rc;
+            a.bmask = (unsigned long long*)(ws + P.off_bmask); a.bmask_rows = P.n_rows;
+        }
+        rc = P.hub ? launch_sweep_hub(P, a, B, st) : bs.ok ? launch_sweep_band(bs, a, B, st, nfill, P.pruned_fast) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
         SweepCfg fc = sweep_config_minimal(P, ab);
         SweepArgs fa = a;
         fa.flag = (const int32_t*)(ws + P.off_flag);
         fa.chunk = fc.chunk; fa.kpad = fc.kpad; fa.smax = fc.smax; fa.arcs_lds_words = 0; fa.hcap = fc.hcap;
+        if (P.pruned_fast) {   // the fallback of a pruned call is the masked log-semiring sweep
+            fa.mA = (const float*)(ws + P.off_mA); fa.mB = (const float*)(ws + P.off_mB);
+            fa.best = (const float*)(ws + P.off_best); fa.thr = (float*)(ws + P.off_thr); fa.beam = output_beam;
+        }
         if (postcheck) {
             // posterior rows first (pass 0 checks every frame and flags what fails), then ONE launch that redoes the
             // flagged utterances in the log semiring (exits at once when nothing is flagged)
@@ -5414,7 +5902,8 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
                 if (rc) return rc;
             } else {
                 RescueArgs r{a.blob, a.utt, (const int32_t*)(ws + P.off_flag), grad_scale, log_probs, strideB, strideT, a.E,
-                             (double*)a.alpha, (double*)a.beta, tot, a.totd, grad};
+                             (double*)a.alpha, (double*)a.beta, tot, a.totd, grad, nullptr, nullptr, nullptr};
+                if (P.pruned_fast) { r.mA = fa.mA; r.mB = fa.mB; r.thr = fa.thr; }
                 hipLaunchKernelGGL(rescue_kernel, dim3(B), dim3(256), 0, st, r);
                 HIP_TRY(hipGetLastError());
             }
@@ -5429,7 +5918,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
                     hk().force_fallback, P.hub ? 1 : 0};
         hipLaunchKernelGGL(check_kernel, dim3((P.Tlong + 1 + kCheckFR - 1) / kCheckFR, B), dim3(64), 0, st, k);
         HIP_TRY(hipGetLastError());
-        rc = launch_sweep<double, float, M_FB>(fc, fa, B, st);
+        rc = P.pruned_fast ? launch_sweep_masked(fc, fa, B, st) : launch_sweep<double, float, M_FB>(fc, fa, B, st);
         if (rc) return rc;
         if ((rc = tm_record(7, st))) return rc;
         g_tm.check_from = 2;
@@ -5708,7 +6197,9 @@ extern "C" int wf_grad_scale(const void* graph_host, const void* graph_dev, cons
     int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
+    // only the per-call tables at the head of the workspace are read (the same offsets under every plan: the call before
+    // may have been planned with WF_PRUNED / WF_DOUBLE_ACC, whose workspaces differ further down)
+    if (ws + P.off_gscale > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.off_gscale + 256);
     GradScaleArgs a{(const int32_t*)graph_dev, (const int64_t*)(ws + P.off_utt), (const int32_t*)(ws + P.off_seq2utt), gs, per_utt ? 1 : 0,
                     grad, strideB, strideT, Tmax};
     hipLaunchKernelGGL(grad_scale_kernel, dim3((Tmax + kPostFR - 1) / kPostFR, num_seqs), dim3(64), 0, (hipStream_t)stream, a);
@@ -5802,17 +6293,17 @@ extern "C" int wf_state_posteriors(const void* graph_host, const void* graph_dev
 }
 
 extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
-                             const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
-                             const int32_t* seg, int32_t B, uint32_t flags, void* tot,
+                             const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t Tmax,
+                             int32_t V, const int32_t* seg, int32_t B, uint32_t flags, void* tot,
                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!graph_dev || !log_probs || !tot || !workspace) return wf_fail(WF_EINVAL, "wf_tot_scores: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const bool dbl = flags & WF_DOUBLE_ACC;
     const size_t ab = (dbl || !(flags & WF_TROPICAL)) ? 8 : 4;
     Plan P;
-    int maxseq = 0;
-    if (seg) for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, 1, &P);
+    int rc = check_segments("wf_tot_scores", seg, B, num_seqs, Tmax);
+    if (rc) return rc;
+    rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, 1, &P);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
@@ -5845,7 +6336,7 @@ extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, cons
 }
 
 extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
-                          const float* log_probs, int64_t strideB, int64_t strideT, int32_t V,
+                          const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V,
                           const int32_t* seg, int32_t B, int32_t Tmax, uint32_t flags, float* best_score,
                           int32_t* best_arcs, void* workspace, size_t workspace_bytes, void* stream) {
     if (!graph_dev || !log_probs || !best_score || !best_arcs || !workspace || !seg) return wf_fail(WF_EINVAL, "wf_viterbi: null pointer");
@@ -5853,12 +6344,11 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
     const bool dbl = flags & WF_DOUBLE_ACC;
     const size_t ab = dbl ? 8 : 4;
     Plan P;
-    int maxseq = 0;
-    for (int i = 0; i < B; ++i) {
-        maxseq = std::max(maxseq, seg[3 * i] + 1);
-        if (seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d longer than Tmax=%d", i, Tmax);
-    }
-    int rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, 2, &P);
+    int rc = check_segments("wf_viterbi", seg, B, num_seqs, Tmax);
+    if (rc) return rc;
+    int maxseq = 0;   // (sizes the plan exactly as wf_viterbi_workspace_bytes does)
+    for (int i = 0; i < B; ++i) maxseq = std::max(maxseq, seg[3 * i] + 1);
+    rc = make_plan(graph_host, utt2fsa, seg, B, V, maxseq, ab, 2, &P);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + P.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, P.total + 256);
@@ -5956,7 +6446,7 @@ extern "C" int wf_search_workspace_bytes(const void* graph_host, const int32_t* 
 }
 
 extern "C" int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
-                         int64_t strideB, int64_t strideT, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
+                         int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
                          float search_beam, int32_t min_active_states, int32_t max_active_states, uint32_t flags,
                          float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
                          size_t workspace_bytes, void* stream) {
@@ -5964,10 +6454,10 @@ extern "C" int wf_search(const void* graph_host, const void* graph_dev, const in
     if (!(search_beam > 0.f)) return wf_fail(WF_EINVAL, "wf_search: search_beam must be > 0 (inf: no beam)");
     if (min_active_states < 0) return wf_fail(WF_EINVAL, "wf_search: min_active_states < 0");
     hipStream_t st = (hipStream_t)stream;
-    for (int i = 0; i < B; ++i)
-        if (seg[3 * i + 2] > Tmax) return wf_fail(WF_ERANGE, "segment %d longer than Tmax=%d", i, Tmax);
+    int rc = check_segments("wf_search", seg, B, num_seqs, Tmax);
+    if (rc) return rc;
     SearchPlan S;
-    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, tot_log != nullptr, &S);
+    rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, tot_log != nullptr, &S);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + S.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, S.total + 256);

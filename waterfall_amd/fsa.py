@@ -185,7 +185,7 @@ class Fsa:
     def workspace_bytes(self, seg, num_seqs, V, flags, need_grad):
         """wf_fb_workspace_bytes, cached per (segments, N, V, flags): a training loop asks with the same values twice per
         step (numerator graphs are new objects every step; a denominator topology is asked thousands of times)."""
-        key = (seg.tobytes(), num_seqs, V, flags, bool(need_grad))
+        key = (seg.tobytes(), num_seqs, V, flags, bool(need_grad), _lib.ENV_EPOCH)
         c = self.__dict__.setdefault("_ws_cache", {})
         n = c.get(key)
         if n is None:
@@ -250,8 +250,6 @@ class DenseFsaVec:
     here the pair (log_probs, segments) *is* the dense FSA vector.
     """
 
-    _validated = None
-
     def __init__(self, log_probs, supervision_segments):
         assert log_probs.dim() == 3, "log_probs must be [N, T, V]"
         assert log_probs.dtype == torch.float32
@@ -263,13 +261,12 @@ class DenseFsaVec:
             log_probs = log_probs.contiguous()
         N, T, V = log_probs.shape
         s = seg.numpy()
-        # (a training loop hands over the same segments tensor step after step: validated once per version)
-        key = (id(seg), seg._version, N, T)
-        if s.size and DenseFsaVec._validated != key:
-            lo, hi = s.min(0), s.max(0)
-            assert lo.min() >= 0 and hi[0] < N and (hi[1] + hi[2] <= T or int((s[:, 1] + s[:, 2]).max()) <= T), \
+        # validated on every construction (three reductions over a [B,3] array): a cache keyed on the tensor's identity
+        # would let a new tensor that reuses a freed one's id() through unchecked, and this is the guard in front of the
+        # library's device reads (the C entry points repeat it: wf_fb_logsum / wf_viterbi / wf_search / wf_tot_scores)
+        if s.size:
+            assert int(s.min()) >= 0 and int(s[:, 0].max()) < N and int((s[:, 1].astype(np.int64) + s[:, 2]).max()) <= T, \
                 "supervision_segments out of range"
-            DenseFsaVec._validated = key
         self.log_probs = log_probs
         self.supervision_segments = seg if seg.is_contiguous() else seg.contiguous()
         self.device = log_probs.device

@@ -128,13 +128,16 @@ class _EagerLossFunction(torch.autograd.Function):
     columns (numerators: the gradient is K non-zeros per row); the others take _FbFunction."""
 
     @staticmethod
-    def forward(ctx, log_probs, graph, dense, reduction, weights):
+    def forward(ctx, log_probs, graph, dense, reduction, weights, beam=0.0):
         lp, seg, B = _check_inputs(graph, dense)
         lib = _lib.lib()
         dev = lp.device
         N, T, V = lp.shape
         gh, gd = graph.blob_host(), graph.blob_dev(dev)
-        nbytes = graph.workspace_bytes(seg, N, V, 0, True)
+        # output_beam (the "pruned" mode): the same fused call with WF_PRUNED -- tropical pass, keep masks, masked sweeps
+        fl = _lib.WF_PRUNED if beam > 0 and math.isfinite(beam) else 0
+        beam = float(beam) if fl else 0.0
+        nbytes = graph.workspace_bytes(seg, N, V, fl, True)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         tot = torch.empty(B, dtype=torch.float32, device=dev)
         grad = torch.empty_like(lp) if lp.is_contiguous() else torch.empty_strided(lp.shape, lp.stride(), dtype=torch.float32, device=dev)
@@ -149,7 +152,7 @@ class _EagerLossFunction(torch.autograd.Function):
         st = _stream(dev)
         with _on(dev):
             _lib.check(lib.wf_fb_logsum(_np_ptr(gh), _ptr(gd), _np_ptr(graph.utt2fsa), _ptr(lp), lp.stride(0), lp.stride(1),
-                                        N, T, V, _np_ptr(seg), B, 0.0, 0, _ptr(gscale), _ptr(tot), _ptr(grad), _ptr(ws),
+                                        N, T, V, _np_ptr(seg), B, beam, fl, _ptr(gscale), _ptr(tot), _ptr(grad), _ptr(ws),
                                         nbytes, st))
             if reduction == 'none':
                 loss = tot.neg()
@@ -161,6 +164,7 @@ class _EagerLossFunction(torch.autograd.Function):
         # everything backward needs is marshalled here, on the caller's thread: Python on the autograd engine's thread
         # runs several times slower (measured: 42 -> 16 us per backward)
         ctx.keep = (graph, dense, ws, gscale, seg, gd)
+        ctx.beam = (beam, fl)
         ctx.expect = expect
         ctx.grad = grad
         ctx.call = [_np_ptr(gh), _ptr(gd), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, N, T, V, lp.stride(0), lp.stride(1), None,
@@ -183,14 +187,14 @@ class _EagerLossFunction(torch.autograd.Function):
             tot = torch.empty(call[4], dtype=torch.float32, device=lp.device)
             with _on(lp.device):
                 _lib.check(_lib.lib().wf_fb_logsum(call[0], call[1], call[2], _ptr(lp), call[8], call[9], call[5], call[6], call[7],
-                                                   call[3], call[4], 0.0, 0, _ptr(gscale), _ptr(tot), _ptr(grad), call[13], call[14],
-                                                   _stream(lp.device)))
+                                                   call[3], call[4], ctx.beam[0], ctx.beam[1], _ptr(gscale), _ptr(tot), _ptr(grad),
+                                                   call[13], call[14], _stream(lp.device)))
             call = list(call)
             call[12] = _ptr(grad)
             call[15] = _stream(lp.device)
         call[10] = C.c_void_p(gs.data_ptr())
         _lib.check(_lib.lib().wf_grad_scale(*call))
-        return grad, None, None, None, None
+        return grad, None, None, None, None, None
 
 
 _NUMDEN_OVERLAP = False
@@ -329,12 +333,17 @@ _BEAM_MODE = "exact"
 def set_output_beam_mode(mode: str):
     """How `output_beam` (graph.py:61-62 passes it to k2.intersect_dense) is honoured.
 
-    "exact" (default): sum over ALL lattice arcs, the limit output_beam -> inf.  With the reference's
-    beams (10, 20) the pruned arcs carry < e^-10 of the best path's mass each, so the two differ by
-    far less than the tolerances (tests/test_gpu_parity.py::test_output_beam_10_is_within_tolerance_of_exact).
-    "pruned": drop lattice arcs whose best path is more than output_beam below the best path
-    (tropical forward-backward pass first); k2 is not available to pin that arithmetic
-    against ("parity unpinned", DESIGN.md).
+    "exact" (default): sum over ALL lattice arcs, the limit output_beam -> inf.  Each pruned arc carries
+    < e^-beam of the best path's mass, but an untrained model spreads such arcs over most of the lattice:
+    measured against the oracle's pruned lattice, the two modes agree inside the tolerances (1e-4 relative
+    on the loss, 1e-3 absolute on the gradient) for beam 20 and for peaked posteriors, and differ by up to
+    5e-2 in single gradient entries for beam 10 on a noise posterior (0.19 at cfg3 size, 0.49 at cfg2 size:
+    tests/test_gpu_parity.py::test_exact_default_is_within_tolerance_of_the_reference_beams, INTEGRATION.md).
+    "pruned": drop lattice arcs whose best path is more than output_beam below the best path (SURVEY 8(0):
+    a tropical forward-backward pass, keep masks, then the masked sweeps and posteriors; on banded graphs --
+    every numerator, the small denominators -- all of it stays on the probability-domain path).  This is
+    the rule the reference's k2.intersect_dense call states (graph.py:61-62); k2 is not available to pin
+    its arithmetic against ("parity unpinned").
     """
     global _BEAM_MODE
     assert mode in ("exact", "pruned")
@@ -371,13 +380,13 @@ def _graphloss(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double
     """graph.py:61-76: loss = -tot_scores (float32), reduced 'none' | 'sum' | 'mean' (/ target_lengths, then batch mean)."""
     beam = _beam_value(output_beam)
     lp = dense_fsa_vec.log_probs
-    if (_EAGER and beam == 0.0 and not use_double_scores and lp.requires_grad and torch.is_grad_enabled()
+    if (_EAGER and not use_double_scores and lp.requires_grad and torch.is_grad_enabled()
             and isinstance(decoding_graph, Fsa) and (decoding_graph.all_compact() or _EAGER_DIRECT)):
         weights = None
         if reduction == 'mean':
             B = dense_fsa_vec.supervision_segments.shape[0]
             weights = (-1.0 / B) / target_lengths.to(device=lp.device, dtype=torch.float32)
-        return _EagerLossFunction.apply(lp, decoding_graph, dense_fsa_vec, reduction, weights)
+        return _EagerLossFunction.apply(lp, decoding_graph, dense_fsa_vec, reduction, weights, beam)
     tot_scores = _FbFunction.apply(lp, decoding_graph, dense_fsa_vec, beam, use_double_scores)
     loss = -1 * tot_scores
     loss = loss.to(torch.float32)
@@ -414,7 +423,7 @@ def tot_scores(graph: Fsa, dense: DenseFsaVec, log_semiring: bool = True, use_do
     tot = torch.empty(B, dtype=torch.float64 if use_double_scores else torch.float32, device=dev)
     with _on(dev):
         _lib.check(lib.wf_tot_scores(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
-                                     _ptr(lp), lp.stride(0), lp.stride(1), V, _np_ptr(seg), B, flags, _ptr(tot),
+                                     _ptr(lp), lp.stride(0), lp.stride(1), N, T, V, _np_ptr(seg), B, flags, _ptr(tot),
                                      _ptr(ws), n.value, _stream(dev)))
     return tot
 
@@ -439,7 +448,7 @@ def best_path(graph: Fsa, dense: DenseFsaVec, use_double_scores: bool = False):
     arcs = torch.empty((B, T + 1), dtype=torch.int32, device=dev)
     with _on(dev):
         _lib.check(lib.wf_viterbi(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
-                                  _ptr(lp), lp.stride(0), lp.stride(1), V, _np_ptr(seg), B, T, flags,
+                                  _ptr(lp), lp.stride(0), lp.stride(1), N, V, _np_ptr(seg), B, T, flags,
                                   _ptr(scores), _ptr(arcs), _ptr(ws), n.value, _stream(dev)))
     labels, aux = _path_labels(graph, arcs)
     return {"scores": scores, "arcs": arcs, "labels": labels, "aux_labels": aux}
@@ -483,7 +492,7 @@ def pruned_search(graph: Fsa, dense: DenseFsaVec, search_beam: float = 20.0, min
     nact = torch.empty((B, T + 1), dtype=torch.int32, device=dev) if return_active else None
     with _on(dev):
         _lib.check(lib.wf_search(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
-                                 _ptr(lp), lp.stride(0), lp.stride(1), V, _np_ptr(seg), B, T, float(search_beam),
+                                 _ptr(lp), lp.stride(0), lp.stride(1), N, V, _np_ptr(seg), B, T, float(search_beam),
                                  int(min_active_states), int(max_active_states), flags, _ptr(scores), _ptr(arcs),
                                  _ptr(tot), _ptr(nact), _ptr(ws), n.value, _stream(dev)))
     res = {"scores": scores, "arcs": arcs}
