@@ -117,11 +117,14 @@ def _np(a):
 class Workload:
     """Synthetic batch (seed 777 + rank) resident on one GPU."""
 
-    def __init__(self, name, B, T, dev, seed, ragged=False, shard=None):
+    def __init__(self, name, B, T, dev, seed, ragged=False, shard=None, beam=0.0):
         """shard = (rank, world): strong scaling -- the batch of B utterances is generated as a whole and this rank keeps
-        the utterances waterfall_amd.dist.shard_batch deals it (round robin over the length-sorted order)."""
+        the utterances waterfall_amd.dist.shard_batch deals it (round robin over the length-sorted order).
+        beam > 0: output_beam pruning (k2.intersect_dense's output_beam, graph.py:61-62,81): WF_PRUNED."""
         w = WORKLOADS[name]
         self.name, self.T, self.dev = name, T, dev
+        self.beam = float(beam)
+        self.flags = _lib.WF_PRUNED if beam > 0 else 0
         P, L = w["P"], w["L"]
         rng = np.random.default_rng(seed)
         phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
@@ -157,7 +160,7 @@ class Workload:
         self.gd = self.fsa.blob_dev(dev)
         n = C.c_size_t(0)
         lib = _lib.lib()
-        _lib.check(lib.wf_fb_workspace_bytes(_np(self.gh), _np(self.fsa.utt2fsa), _np(self.segs), B, B, V, 0, 1, C.byref(n)))
+        _lib.check(lib.wf_fb_workspace_bytes(_np(self.gh), _np(self.fsa.utt2fsa), _np(self.segs), B, B, V, self.flags, 1, C.byref(n)))
         self.ws_bytes = n.value
         self.ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
         self.frames = int(lens.sum())
@@ -178,7 +181,7 @@ class Workload:
         lib = _lib.lib()
         lp = self.lp
         _lib.check(lib.wf_fb_logsum(_np(self.gh), _ptr(self.gd), _np(self.fsa.utt2fsa), _ptr(lp), lp.stride(0),
-                                    lp.stride(1), self.B, self.T, self.V, _np(self.segs), self.B, 0.0, 0,
+                                    lp.stride(1), self.B, self.T, self.V, _np(self.segs), self.B, self.beam, self.flags,
                                     _ptr(self.gscale), _ptr(self.tot), _ptr(self.grad), _ptr(self.ws),
                                     self.ws_bytes, C.c_void_p(stream)))
 
@@ -187,7 +190,7 @@ class Workload:
         kernels' own work, not a repair of it)."""
         n = C.c_int32(-1)
         _lib.check(_lib.lib().wf_debug_fallback_count(_np(self.gh), _np(self.fsa.utt2fsa), _np(self.segs), self.B, self.B, self.V,
-                                                      0, 1, _ptr(self.ws), self.ws_bytes, C.c_void_p(stream), C.byref(n)))
+                                                      self.flags, 1, _ptr(self.ws), self.ws_bytes, C.c_void_p(stream), C.byref(n)))
         return int(n.value)
 
     # ---- algorithmic bytes (DESIGN.md "Kernels"): what each kernel must move, per batch --------
@@ -545,6 +548,9 @@ def main():
                          "efficiency from the two); the kernel's cost is reported at N = 1 as label_grad_sums_ms")
     ap.add_argument("--min-region-ms", type=float, default=100.0,
                     help="repeat the timed K-step region until the regions add up to this (median and min are reported)")
+    ap.add_argument("--output-beam", type=float, default=0.0,
+                    help="> 0: run the step with output_beam pruning (k2.intersect_dense's output_beam, graph.py:61-62,81: WF_PRUNED); "
+                         "0 (default): the exact sum over all lattice arcs")
     ap.add_argument("--others", action="store_true", help="(default at N=1) also time the other BASELINE workloads")
     ap.add_argument("--no-others", action="store_true", help="headline only")
     args = ap.parse_args()
@@ -576,9 +582,9 @@ def main():
     if strong:
         if args.batch < world:
             raise SystemExit(f"--scaling strong: {args.batch} utterances cannot be dealt over {world} ranks")
-        wl = Workload(args.workload, args.batch, args.frames, dev, seed=777, ragged=args.ragged, shard=(rank, world))
+        wl = Workload(args.workload, args.batch, args.frames, dev, seed=777, ragged=args.ragged, shard=(rank, world), beam=args.output_beam)
     else:
-        wl = Workload(args.workload, args.batch, args.frames, dev, seed=777 + rank, ragged=args.ragged)
+        wl = Workload(args.workload, args.batch, args.frames, dev, seed=777 + rank, ragged=args.ragged, beam=args.output_beam)
     grad_sums = world > 1 and args.grad_sums
     fused = torch.zeros(3 + (wl.V if grad_sums else 0), dtype=torch.float32, device=dev)
     times = time_steps(wl, args.steps, args.warmup, dist, stream, fused, min_region_s=args.min_region_ms * 1e-3)
@@ -609,7 +615,8 @@ def main():
                      "the fastest region alongside (value_at_min, ms_per_step_min)",
         "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}, "
                                + (f"B={args.batch} in all, dealt over {world} GPUs, " if strong else f"B={args.batch} per GPU, ")
-                               + f"T={args.frames}{' ragged' if args.ragged else ''}, loss+grad, reduction=sum, exact (no output_beam pruning)",
+                               + f"T={args.frames}{' ragged' if args.ragged else ''}, loss+grad, reduction=sum, "
+                               + (f"output_beam={args.output_beam:g} (pruned lattice)" if args.output_beam > 0 else "exact (no output_beam pruning)"),
                    "scaling": "strong" if strong else "weak",
                    "batch_per_gpu": wl.B, "batch_total": args.batch if (strong or world == 1) else args.batch * world,
                    "frames": args.frames, "V": wl.V,
@@ -630,7 +637,7 @@ def main():
             kb = dict(kb, sweep=kb["sweep"] + kb["zero"], sweep_alone=kb["sweep"])
         ach = kb[dom] / (kt[dom] * 1e-3) / 1e9
         default_wl = (args.workload == "cfg3_ctc_bpe5k_num" and args.batch == 32 and args.frames == 500
-                      and not args.ragged)
+                      and not args.ragged and args.output_beam == 0)
         if default_wl:
             kname = KERNEL_NAMES.get(dom, dom)
         elif wl.S_mean > 4096 and kt["check"] >= 0:      # large denominators (cfg4): DESIGN.md section 4
@@ -714,6 +721,25 @@ def main():
                     del w2
                 except Exception as e:   # noqa: BLE001
                     others[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            # the reference's own semantics: every caller passes output_beam (default 10, graph.py:61-62,81); the same
+            # fused call with WF_PRUNED (tropical pass + keep masks + masked sweeps; tests/test_pruned.py)
+            for name, key in (("cfg3_ctc_bpe5k_num", "cfg3_pruned_beam10"), ("cfg2_2state_char_num", "cfg2_num_pruned_beam10"),
+                              ("cfg2_2state_char_den", "cfg2_den_pruned_beam10")):
+                try:
+                    w2 = Workload(name, 32, args.frames, dev, seed=777, beam=10.0)
+                    n2 = max(5, args.steps // 5)
+                    d2 = float(np.median(time_steps(w2, n2, 3, None, stream, fused[:3], min_region_s=0.03)))
+                    exact_ms = ms_step if name == args.workload else others.get(name, {}).get("ms_per_step")
+                    others[key] = {"frames_per_s": w2.frames / (d2 / n2), "ms_per_step": d2 / n2 * 1e3,
+                                   "exact_ms_per_step": exact_ms, "ratio_to_exact": (d2 / n2 * 1e3 / exact_ms) if exact_ms else None,
+                                   "fallback_utterances": w2.fallbacks(stream),
+                                   "desc": WORKLOADS[name]["desc"] + ", output_beam=10 (WF_PRUNED): lattice arcs more than 10 below "
+                                           "the tropical best path are dropped, as k2.intersect_dense(output_beam=10) states",
+                                   "checked_by": "tests/test_pruned.py::test_pruned_at_baseline_size_against_oracle"}
+                    del w2
+                except Exception as e:   # noqa: BLE001
+                    others[key] = {"error": repr(e)}
                 torch.cuda.empty_cache()
             for S in (100_000, 1_000_000):
                 try:
