@@ -542,10 +542,10 @@ def _peaked_like_a_trained_model(c, mass=0.99):
 @pytest.mark.parametrize("posterior", ["noise", "peaked"])
 @pytest.mark.parametrize("beam", [10.0, 20.0])
 @pytest.mark.parametrize("topo", ALL_TOPOLOGIES)
-def test_exact_default_is_within_tolerance_of_the_reference_beams(topo, beam, posterior):
-    """graphloss(output_beam=10 | 20) runs the EXACT sum by default where the reference prunes (graph.py:61-62; beams of
-    the recipes' configs).  The claim behind that default -- the pruned mass is below the tolerance of north_star -- on
-    every topology, both beams, a noise posterior and a peaked one, against the oracle's pruned lattice.
+def test_exact_mode_is_within_tolerance_of_the_reference_beams(topo, beam, posterior):
+    """graphloss(output_beam=10 | 20) in the "exact" mode sums over all lattice arcs where the reference prunes
+    (graph.py:61-62; beams of the recipes' configs).  How far that is from the pruned lattice -- below the tolerance of
+    north_star or not -- on every topology, both beams, a noise posterior and a peaked one, against the oracle.
     [k2's own beam arithmetic: parity unpinned]"""
     c = util.random_case(900 + ALL_TOPOLOGIES.index(topo), topo, B=3, T=60, L=8, P=9)
     lp = c["lp"] if posterior == "noise" else _peaked_like_a_trained_model(c)
@@ -563,7 +563,7 @@ def test_exact_default_is_within_tolerance_of_the_reference_beams(topo, beam, po
 
 @pytest.mark.parametrize("beam", [10.0, 20.0])
 @pytest.mark.parametrize("topo", ["2state", "mmictc", "3state-skip", "ctc"])
-def test_exact_default_vs_reference_beams_on_denominators(topo, beam):
+def test_exact_mode_vs_reference_beams_on_denominators(topo, beam):
     c = util.random_case(950, topo, B=3, T=60, L=8, P=9, den=True)
     pruned, pgrad = o.graphloss(c["ographs"], c["lp"], c["segs"], beam, "none")
     loss, grad = run_hip(c["fsa"], c["lp"], c["segs"], "none")

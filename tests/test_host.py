@@ -282,3 +282,16 @@ def test_decoding_graph_file_round_trip_weights_only(tmp_path):
     torch.save({"arcs": torch.from_numpy(g.arcs.copy()), "aux_labels": _RaggedStandIn()}, p)
     with pytest.raises(ValueError, match="weights_only"):
         decode.load_decoding_graph(p)
+
+
+def test_output_beam_default_mode_is_the_reference_semantics():
+    """graphloss(..., output_beam=10) (graph.py:81) prunes by default, as k2.intersect_dense(graph, dense, output_beam)
+    does (graph.py:61-62); "exact" (what the autouse fixture selects for the parity tests) ignores the beam."""
+    from waterfall_amd import graph as g
+    assert g.DEFAULT_BEAM_MODE == "pruned"
+    assert g._BEAM_MODE == "exact" and g._beam_value(10) == 0.0          # inside a test: the fixture's mode
+    wf.set_output_beam_mode(g.DEFAULT_BEAM_MODE)
+    try:
+        assert g._beam_value(10) == 10.0 and g._beam_value(None) == 0.0
+    finally:
+        wf.set_output_beam_mode("exact")

@@ -2117,20 +2117,24 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
                 mlo = *(const int*)(mb + (size_t)k * 512 + lane * 8);
                 if (NQ * MM > 32) mhi = *(const int*)(mb + (size_t)k * 512 + lane * 8 + 4);
             }
-            // byte offset of cell (j, m)'s value inside the staged row: a pruned cell reads the zero at offset 0
-            auto off = [&](const int j, const int m) __attribute__((always_inline)) -> unsigned {
-                if (!MASK) return coff[j][m];
+            // address of cell (j, m)'s value: a pruned cell reads the zero at offset 0 of the row.  MASK: the row's offset
+            // from the start of the LDS is a multiple of the row size, so it is OR-ed in (v_bfe_i32 + v_and_or_b32: two
+            // instructions per cell; an add behind the AND would be a third)
+            const unsigned rowoff = (unsigned)(pb - smem);
+            auto val = [&](const int j, const int m) __attribute__((always_inline)) -> double {
+                if (!MASK) return *(const double*)(pb + (size_t)k * kBandKP * 8 + coff[j][m]);
                 const int bit = j * MM + m;
-                return coff[j][m] & (unsigned)__builtin_amdgcn_sbfe(bit < 32 ? mlo : mhi, bit & 31, 1);
+                const unsigned o = (coff[j][m] & (unsigned)__builtin_amdgcn_sbfe(bit < 32 ? mlo : mhi, bit & 31, 1)) | rowoff;
+                return *(const double*)(smem + o + (size_t)k * kBandKP * 8);
             };
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 if (WE) {
-                    q[j] = *(const double*)(pb + (size_t)k * kBandKP * 8 + off(j, 0));
+                    q[j] = val(j, 0);
                 } else {
-                    double v = cw[j][0] * *(const double*)(pb + (size_t)k * kBandKP * 8 + off(j, 0));
+                    double v = cw[j][0] * val(j, 0);
 #pragma unroll
-                    for (int m = 1; m < MM; ++m) v = fma(cw[j][m], *(const double*)(pb + (size_t)k * kBandKP * 8 + off(j, m)), v);
+                    for (int m = 1; m < MM; ++m) v = fma(cw[j][m], val(j, m), v);
                     q[j] = v;
                 }
             }
@@ -2413,7 +2417,8 @@ __device__ __forceinline__ float bperm_f(float v, int srclane) {
 
 constexpr size_t kTropEBytes = (size_t)kBandC * kBandKP * 4;   // one chunk of staged emission rows (fp32)
 
-template <int R, int BW, int MM, bool GEN = false>
+// WE: every arc weight is 0 (all training topologies): the staged emission is the arc score itself
+template <int R, int BW, int MM, bool WE, bool GEN = false>
 __global__ void __launch_bounds__(128) trop_band_kernel(SweepArgs p) {
     constexpr int GD = WF_REG_DEG;
     constexpr int NQ = GEN ? GD + 1 : R * (BW + 1), C = kBandC;
@@ -2469,7 +2474,10 @@ __global__ void __launch_bounds__(128) trop_band_kernel(SweepArgs p) {
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
 #pragma unroll
-                for (int m = 0; m < MM; ++m) x[j][m] = cw[j][m] + *(const float*)(pb + (size_t)k * kBandKP * 4 + coff[j][m]);
+                for (int m = 0; m < MM; ++m) {
+                    const float e = *(const float*)(pb + (size_t)k * kBandKP * 4 + coff[j][m]);
+                    x[j][m] = WE ? e : cw[j][m] + e;
+                }
         };
         auto step = [&](const float (&x)[NQ][MM]) __attribute__((always_inline)) {
             if (GEN) {
@@ -2489,13 +2497,19 @@ __global__ void __launch_bounds__(128) trop_band_kernel(SweepArgs p) {
             float an[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float v = -INFINITY;
+                constexpr int NT = (BW + 1) * MM;
+                float t[NT < 3 ? 3 : NT] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
                 for (int d = 0; d <= BW; ++d) {
                     const float sv = (r - d >= 0) ? a[r - d >= 0 ? r - d : 0] : nb[d - r - 1 >= 0 ? d - r - 1 : 0];
 #pragma unroll
-                    for (int m = 0; m < MM; ++m) v = fmaxf(v, sv + x[r * (BW + 1) + d][m]);
+                    for (int m = 0; m < MM; ++m) t[d * MM + m] = sv + x[r * (BW + 1) + d][m];
                 }
+                // a tree of three-input maxima (v_max3_f32)
+                float v = fmaxf(fmaxf(t[0], t[1]), t[2]);
+#pragma unroll
+                for (int i = 3; i + 1 < NT; i += 2) v = fmaxf(fmaxf(v, t[i]), t[i + 1]);
+                if ((NT & 1) == 0) v = fmaxf(v, t[NT - 1]);
                 an[r] = v;
             }
 #pragma unroll
@@ -2513,10 +2527,15 @@ __global__ void __launch_bounds__(128) trop_band_kernel(SweepArgs p) {
             load_x(pb, 0, x0);
 #pragma unroll
             for (int k = 0; k < C; k += 2) {
+                // (the scheduler otherwise sinks every LDS read to its use and waits for each in turn)
                 load_x(pb, k + 1, x1);
+                __builtin_amdgcn_sched_barrier(0);
                 step(x0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (k + 2 < C) load_x(pb, k + 2, x0);
+                __builtin_amdgcn_sched_barrier(0);
                 step(x1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (nfull < nc) {
@@ -2614,13 +2633,20 @@ struct BandMaskArgs {
     float* thr;          // [B] out: best - beam (post kernels, rescue)
     unsigned long long* mask;   // [2][rows][64]
     int64_t rows;
+    int sp, kp;          // LDS pitches of a staged state row / emission row (floats)
 };
 
-constexpr int kMaskFR = 4;   // frames per wavefront
+constexpr int kMaskFR = 8;   // frames per wavefront
 
+// One wavefront per kMaskFR frames of an utterance.  The three rows a frame's keep test reads (alpha^_t, beta^_{t+1}, the
+// emissions) are brought into the LDS with coalesced loads, all frames' loads in flight together, and the per-cell
+// gathers then run against the LDS (gathers from memory: 54 instructions of 64 scattered lanes per frame, bound by the
+// texture addresser at ~16 cycles each -- 40 us on cfg3 against 8).
 template <int R, int BW, int MM, bool GEN = false>
 __global__ void __launch_bounds__(64) band_mask_kernel(BandMaskArgs p) {
     constexpr int NQ = GEN ? WF_REG_DEG + 1 : R * (BW + 1);
+    extern __shared__ __align__(16) unsigned char smem[];   // [kMaskFR][2 * sp + kp] floats
+    float* sh = (float*)smem;
     const int lane = threadIdx.x;
     const int t0 = blockIdx.x * kMaskFR, u = blockIdx.y;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
@@ -2630,10 +2656,36 @@ __global__ void __launch_bounds__(64) band_mask_kernel(BandMaskArgs p) {
     if (t0 == 0 && lane == 0) p.thr[u] = thr;
     if (t0 >= T || T < I[WF_I_MINLEN]) return;
     const int S = I[WF_I_S], K = I[WF_I_K], direct = I[WF_I_DIRECT];
+    const int sp = p.sp, pitch = 2 * p.sp + p.kp;
     const float* ebase = direct ? p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT : p.E + U[WF_U_E];
     const int64_t epitch = direct ? p.strideT : (int64_t)K;
     const float* abase = p.mA + U[WF_U_ALPHA];
     const float* bbase = p.mB + U[WF_U_BETA];
+    const int nf = min(kMaskFR, T - t0);
+    // ---- rows -> LDS (loads unconditional: indices clamped into the row, frames past the end repeat the last one)
+    constexpr int NS = (64 * WF_BAND_MAX_R + 1 + 63) / 64, NK = (kBandKP + 63) / 64;
+    if (K > 0) {
+#pragma unroll
+        for (int f = 0; f < kMaskFR; ++f) {
+            const int t = t0 + min(f, nf - 1);
+            float va[NS], vb[NS], ve[NK];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int s_ = min(lane + 64 * i, S - 1);
+                va[i] = abase[(int64_t)t * S + s_];
+                vb[i] = bbase[(int64_t)(t + 1) * S + s_];
+            }
+#pragma unroll
+            for (int i = 0; i < NK; ++i) ve[i] = ebase[(int64_t)t * epitch + min(lane + 64 * i, K - 1)];
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                if (lane + 64 * i < S) { sh[f * pitch + lane + 64 * i] = va[i]; sh[f * pitch + sp + lane + 64 * i] = vb[i]; }
+#pragma unroll
+            for (int i = 0; i < NK; ++i)
+                if (lane + 64 * i < K) sh[f * pitch + 2 * sp + lane + 64 * i] = ve[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // one wavefront: its LDS operations execute in order
 #pragma unroll
     for (int dir = 0; dir < 2; ++dir) {
         int src[NQ][MM], dst[NQ][MM], col[NQ][MM];
@@ -2644,23 +2696,21 @@ __global__ void __launch_bounds__(64) band_mask_kernel(BandMaskArgs p) {
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
                 const BandCell c = band_cell<R, BW, MM, GEN>(p.blob, I, dir, lane, j, m);
-                src[j][m] = c.src; dst[j][m] = c.dst; col[j][m] = c.col; w[j][m] = c.w;   // an empty cell: state 0, column 0
+                src[j][m] = c.src; dst[j][m] = sp + c.dst; col[j][m] = 2 * sp + c.col; w[j][m] = c.w;   // an empty cell: state 0, column 0
                 if (c.on) on |= 1ull << (j * MM + m);
             }
         unsigned long long* out = p.mask + ((int64_t)dir * p.rows + U[WF_U_ROW0]) * 64 + lane;
-        for (int t = t0; t < min(t0 + kMaskFR, T); ++t) {
-            const float* arow = abase + (int64_t)t * S;
-            const float* brow = bbase + (int64_t)(t + 1) * S;
-            const float* erow = ebase + (int64_t)t * epitch;
+        for (int f = 0; f < nf; ++f) {
+            const float* row = sh + f * pitch;
             unsigned long long keep = 0;
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
 #pragma unroll
                 for (int m = 0; m < MM; ++m) {
-                    const float x = w[j][m] + erow[col[j][m]];
-                    if (arow[src[j][m]] + x + brow[dst[j][m]] >= thr) keep |= 1ull << (j * MM + m);
+                    const float x = w[j][m] + row[col[j][m]];
+                    if (row[src[j][m]] + x + row[dst[j][m]] >= thr) keep |= 1ull << (j * MM + m);
                 }
-            out[(int64_t)t * 64] = keep & on;
+            out[(int64_t)(t0 + f) * 64] = keep & on;
         }
     }
 }
@@ -5359,20 +5409,21 @@ int launch_sweep_band(const BandSel& b, SweepArgs a, int B, hipStream_t st, int 
 
 // output_beam pruning on the banded path, first two launches: the tropical forward-backward rows (a.alpha / a.beta / a.tot
 // = the fp32 arenas and best[]), then the keep-mask words
-template <int R, int BW, int MM, bool GEN = false>
+template <int R, int BW, int MM, bool WE, bool GEN = false>
 int launch_trop_one(const SweepArgs& a, const BandMaskArgs& m, int B, int Tlong, hipStream_t st) {
-    auto k = trop_band_kernel<R, BW, MM, GEN>;
+    auto k = trop_band_kernel<R, BW, MM, WE, GEN>;
     { int rc_ = ensure_lds((const void*)k, kBandLds); if (rc_) return rc_; }
     hipLaunchKernelGGL(k, dim3(B * 2), dim3(128), kBandLds, st, a);
-    hipLaunchKernelGGL((band_mask_kernel<R, BW, MM, GEN>), dim3((std::max(Tlong, 1) + kMaskFR - 1) / kMaskFR, B), dim3(64), 0, st, m);
+    hipLaunchKernelGGL((band_mask_kernel<R, BW, MM, GEN>), dim3((std::max(Tlong, 1) + kMaskFR - 1) / kMaskFR, B), dim3(64),
+                       (size_t)kMaskFR * (2 * m.sp + m.kp) * sizeof(float), st, m);
     HIP_TRY(hipGetLastError());
     return WF_OK;
 }
 
 int launch_trop_band(const BandSel& b, const SweepArgs& a, const BandMaskArgs& m, int B, int Tlong, hipStream_t st) {
-    if (b.gen) return launch_trop_one<1, 1, 1, true>(a, m, B, Tlong, st);
+    if (b.gen) return b.we ? launch_trop_one<1, 1, 1, true, true>(a, m, B, Tlong, st) : launch_trop_one<1, 1, 1, false, true>(a, m, B, Tlong, st);
 #define WF_TROP_CASE(RR, WW) \
-    if (b.BW == WW && b.R == RR) return b.M == 1 ? launch_trop_one<RR, WW, 1>(a, m, B, Tlong, st) : launch_trop_one<RR, WW, 2>(a, m, B, Tlong, st)
+    if (b.BW == WW && b.R == RR) return b.we ? launch_trop_one<RR, WW, 1, true>(a, m, B, Tlong, st) : b.M == 1 ? launch_trop_one<RR, WW, 1, false>(a, m, B, Tlong, st) : launch_trop_one<RR, WW, 2, false>(a, m, B, Tlong, st)
     WF_TROP_CASE(2, 2);
     WF_TROP_CASE(3, 2);
     WF_TROP_CASE(4, 2);
@@ -5385,9 +5436,11 @@ int launch_trop_band(const BandSel& b, const SweepArgs& a, const BandMaskArgs& m
 int ensure_band_lds() {
     int rc = 0;
 #define WF_TROP_ATTR(...) if ((rc = ensure_lds((const void*)trop_band_kernel<__VA_ARGS__>, kBandLds))) return rc
-    WF_TROP_ATTR(1, 1, 1, true);
-    WF_TROP_ATTR(2, 2, 1); WF_TROP_ATTR(2, 2, 2); WF_TROP_ATTR(3, 2, 1); WF_TROP_ATTR(3, 2, 2);
-    WF_TROP_ATTR(4, 2, 1); WF_TROP_ATTR(4, 2, 2); WF_TROP_ATTR(4, 4, 1); WF_TROP_ATTR(4, 4, 2);
+    WF_TROP_ATTR(1, 1, 1, true, true); WF_TROP_ATTR(1, 1, 1, false, true);
+    WF_TROP_ATTR(2, 2, 1, true); WF_TROP_ATTR(2, 2, 1, false); WF_TROP_ATTR(2, 2, 2, false);
+    WF_TROP_ATTR(3, 2, 1, true); WF_TROP_ATTR(3, 2, 1, false); WF_TROP_ATTR(3, 2, 2, false);
+    WF_TROP_ATTR(4, 2, 1, true); WF_TROP_ATTR(4, 2, 1, false); WF_TROP_ATTR(4, 2, 2, false);
+    WF_TROP_ATTR(4, 4, 1, true); WF_TROP_ATTR(4, 4, 1, false); WF_TROP_ATTR(4, 4, 2, false);
 #undef WF_TROP_ATTR
 #define WF_BAND_ATTR(...) if ((rc = ensure_lds((const void*)sweep_band_kernel<__VA_ARGS__>, kBandLds))) return rc
     WF_BAND_ATTR(1, 1, 1, true, true); WF_BAND_ATTR(1, 1, 1, false, true);
@@ -5869,7 +5922,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
             ta.alpha = ws + P.off_mA; ta.beta = ws + P.off_mB; ta.tot = ws + P.off_best; ta.totd = nullptr;
             BandMaskArgs bm{a.blob, a.utt, log_probs, strideB, strideT, a.E, (const float*)(ws + P.off_mA), (const float*)(ws + P.off_mB),
                             (const float*)(ws + P.off_best), output_beam, (float*)(ws + P.off_thr),
-                            (unsigned long long*)(ws + P.off_bmask), P.n_rows};
+                            (unsigned long long*)(ws + P.off_bmask), P.n_rows, (int)align_up(P.smax, 4), (int)align_up(std::max(P.kmax, 1), 4)};
             if ((rc = launch_trop_band(bs, ta, bm, B, P.Tlong, st))) return rc;
             a.bmask = (unsigned long long*)(ws + P.off_bmask); a.bmask_rows = P.n_rows;
         }

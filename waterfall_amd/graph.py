@@ -327,23 +327,25 @@ def set_eager_gradient(on: bool):
     _EAGER = bool(on)
 
 
-_BEAM_MODE = "exact"
+DEFAULT_BEAM_MODE = "pruned"   # what the reference's own call does: k2.intersect_dense(graph, dense, output_beam)
+_BEAM_MODE = DEFAULT_BEAM_MODE
 
 
 def set_output_beam_mode(mode: str):
     """How `output_beam` (graph.py:61-62 passes it to k2.intersect_dense) is honoured.
 
-    "exact" (default): sum over ALL lattice arcs, the limit output_beam -> inf.  Each pruned arc carries
-    < e^-beam of the best path's mass, but an untrained model spreads such arcs over most of the lattice:
-    measured against the oracle's pruned lattice, the two modes agree inside the tolerances (1e-4 relative
-    on the loss, 1e-3 absolute on the gradient) for beam 20 and for peaked posteriors, and differ by up to
-    5e-2 in single gradient entries for beam 10 on a noise posterior (0.19 at cfg3 size, 0.49 at cfg2 size:
-    tests/test_gpu_parity.py::test_exact_default_is_within_tolerance_of_the_reference_beams, INTEGRATION.md).
-    "pruned": drop lattice arcs whose best path is more than output_beam below the best path (SURVEY 8(0):
-    a tropical forward-backward pass, keep masks, then the masked sweeps and posteriors; on banded graphs --
-    every numerator, the small denominators -- all of it stays on the probability-domain path).  This is
-    the rule the reference's k2.intersect_dense call states (graph.py:61-62); k2 is not available to pin
-    its arithmetic against ("parity unpinned").
+    "pruned" (default since round 3): drop lattice arcs whose best path is more than output_beam below the best
+    path (a tropical forward-backward pass, keep masks, then the masked sweeps and posteriors; on
+    banded graphs -- every numerator, the small denominators -- all of it stays on the probability-domain path:
+    2.0x the exact step at cfg3 / cfg2 sizes).  This is the rule the reference's k2.intersect_dense call states
+    (graph.py:61-62, default beam 10 at :81); k2 is not available to pin its arithmetic against ("parity
+    unpinned").  output_beam=None or inf: no pruning.
+    "exact": sum over ALL lattice arcs whatever the beam -- the limit output_beam -> inf, half the cost.  Each
+    pruned arc carries < e^-beam of the best path's mass, but an untrained model spreads such arcs over most of
+    the lattice: against the oracle's pruned lattice the two modes agree inside the tolerances (1e-4 relative on
+    the loss, 1e-3 absolute on the gradient) for beam 20 and for peaked posteriors, and differ by up to 5e-2 in
+    single gradient entries for beam 10 on a noise posterior (0.19 at cfg3 size, 0.49 at cfg2 size:
+    tests/test_gpu_parity.py::test_exact_mode_is_within_tolerance_of_the_reference_beams, INTEGRATION.md).
     """
     global _BEAM_MODE
     assert mode in ("exact", "pruned")
