@@ -210,6 +210,10 @@ int wf_fb_logsum(const void* graph_host, const void* graph_dev, const int32_t* u
  * threads) race; stream-ordered calls are safe.                                                                     */
 #define WF_STATIC_SCRATCH_BYTES (96u << 20)
 int wf_static_scratch_bytes(size_t* bytes);
+/* Test aid (no counterpart in the reference): the number of allocating calls the library has made in this process so far
+ * (pinned staging ring, side streams, events; it never allocates device memory).  Unchanged across a call = that call
+ * allocated nothing. */
+int wf_debug_alloc_count(int64_t* count);
 int wf_fb_logsum_static(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa,
                         const float* log_probs, int64_t strideB, int64_t strideT, int32_t num_seqs,
                         int32_t Tmax, int32_t V, const int32_t* seg, int32_t B, float output_beam,

@@ -295,3 +295,29 @@ def test_output_beam_default_mode_is_the_reference_semantics():
         assert g._beam_value(10) == 10.0 and g._beam_value(None) == 0.0
     finally:
         wf.set_output_beam_mode("exact")
+
+
+def test_numerator_compiler_works_in_a_forked_child():
+    """A torch DataLoader worker / multiprocessing child forked AFTER the parent used the compiler's thread pool inherits
+    the pool object without its threads: the pool must notice and start its own instead of waiting for them forever."""
+    import signal
+    topo = wf.Topology("2state", ["<eps>", "<SIL>"] + ["p%d" % i for i in range(9)])
+    seqs = [[2, 3, 4], [5, 5], [6, 7, 8, 9], [2], [3, 4], [10, 9, 8], [4, 4, 4], [7]]
+    want = wf.compile_ctc_k2_graphs(topo, seqs)          # the parent's pool now has worker threads
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        code = 1
+        try:
+            signal.alarm(60)                              # a deadlock ends the child, not the test run
+            got = wf.compile_ctc_k2_graphs(topo, seqs)
+            code = 0 if (np.array_equal(got.arcs, want.arcs) and np.array_equal(got.aux_labels, want.aux_labels)
+                         and np.array_equal(got.fsa_arc_offsets, want.fsa_arc_offsets)) else 2
+        finally:
+            os.write(w, bytes([code]))
+            os._exit(code)
+    os.close(w)
+    _, status = os.waitpid(pid, 0)
+    out = os.read(r, 1)
+    os.close(r)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0 and out == b"\x00"

@@ -33,10 +33,20 @@ def static_logsum(fsa, lp, segs, gscale=-1.0, init=True):
         if init:
             _lib.check(lib.wf_init())
         torch.cuda.synchronize()
+        # "allocates nothing", three ways: torch's caching allocator saw no request; the device's free memory as the HIP
+        # runtime reports it (hipMemGetInfo: sees any hipMalloc, the library's included) is unchanged; the library's own
+        # counter of allocating calls (pinned ring, streams, events) did not move
         before = torch.cuda.memory_allocated(DEV)
+        free_before = torch.cuda.mem_get_info(DEV)[0]
+        n0, n1 = C.c_int64(-1), C.c_int64(-2)
+        _lib.check(lib.wf_debug_alloc_count(C.byref(n0)))
         rc = lib.wf_fb_logsum_static(npp(gh), p(gd), npp(fsa.utt2fsa), p(x), x.stride(0), x.stride(1), N, T, V, npp(segs), B,
                                      0.0, 0, p(gs), p(tot), p(grad), st)
+        _lib.check(lib.wf_debug_alloc_count(C.byref(n1)))
+        torch.cuda.synchronize()
         assert torch.cuda.memory_allocated(DEV) == before
+        assert torch.cuda.mem_get_info(DEV)[0] == free_before
+        assert n1.value == n0.value
     if rc:
         return rc, lib.wf_last_error().decode()
     torch.cuda.synchronize()

@@ -58,6 +58,7 @@ _SIGS = {
                                        _p, _sz, C.POINTER(_sz), _i32]),
     "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),
     "wf_static_scratch_bytes": (C.c_int, [C.POINTER(_sz)]),
+    "wf_debug_alloc_count": (C.c_int, [C.POINTER(C.c_int64)]),
     "wf_fb_logsum_static": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, C.c_float, _u32,
                                       _p, _p, _p, _p]),
     "wf_fb_logsum": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, C.c_float, _u32,

@@ -168,7 +168,9 @@ def _alloc_blob(words):
     """int32 buffer for a prepared blob: pinned (so that Fsa.blob_dev uploads it with one asynchronous copy; torch's
     caching host allocator recycles it only after that copy has finished) when a GPU is present, plain numpy otherwise."""
     import torch
-    if torch.cuda.is_available():
+    # pinned only where this process already talks to the GPU: a forked DataLoader worker that compiles graphs must not
+    # initialise (and cannot use) the parent's CUDA context
+    if torch.cuda.is_available() and torch.cuda.is_initialized() and not torch.cuda._is_in_bad_fork():
         pin = torch.empty(words, dtype=torch.int32, pin_memory=True)
         return pin, pin.numpy()
     return None, np.empty(words, dtype=np.int32)

@@ -21,6 +21,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/wf_dwfst.h"
 #include "wf_internal.h"
 
@@ -839,55 +841,70 @@ class WorkerPool {
     // runs fn(worker, nworkers) on `want` workers (the caller is worker 0) and waits for all of them
     void run(int want, const std::function<void(int, int)>& fn) {
         want = std::max(1, std::min(want, kMax));
-        std::unique_lock<std::mutex> own(region_, std::try_to_lock);
+        if (pid_ != getpid()) {
+            // A child forked after the parent used the pool (a DataLoader worker) inherits the pool's memory but none of
+            // its threads, and condition variables that still count the parent's sleeping workers as waiters (a notify
+            // would wait for them forever): leave that state behind untouched and start this process's own.
+            st_ = new State();
+            pid_ = getpid();
+        }
+        State& S = *st_;
+        std::unique_lock<std::mutex> own(S.region, std::try_to_lock);
         if (want == 1 || !own.owns_lock()) { fn(0, 1); return; }
         {
-            std::lock_guard<std::mutex> lk(m_);
-            while ((int)threads_.size() < want - 1) {
-                const int id = (int)threads_.size() + 1;
-                threads_.emplace_back([this, id] { loop(id); });
+            std::lock_guard<std::mutex> lk(S.m);
+            while ((int)S.threads.size() < want - 1) {
+                const int id = (int)S.threads.size() + 1;
+                State* sp = st_;
+                S.threads.emplace_back([sp, id] { loop(*sp, id); });
             }
-            fn_ = &fn; n_ = want; pending_ = want - 1; ++gen_;
+            S.fn = &fn; S.n = want; S.pending = want - 1; ++S.gen;
         }
-        cv_.notify_all();
+        S.cv.notify_all();
         fn(0, want);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        std::unique_lock<std::mutex> lk(S.m);
+        S.done.wait(lk, [&S] { return S.pending == 0; });
+        S.fn = nullptr;
     }
     ~WorkerPool() {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto& t : threads_) t.join();
+        if (pid_ != getpid()) return;   // (a forked child that never used the pool: nothing of its own to stop)
+        State& S = *st_;
+        { std::lock_guard<std::mutex> lk(S.m); S.stop = true; }
+        S.cv.notify_all();
+        for (auto& t : S.threads) t.join();
     }
   private:
     static constexpr int kMax = 16;
-    void loop(int id) {
+    struct State {
+        std::mutex m, region;
+        std::condition_variable cv, done;
+        std::vector<std::thread> threads;
+        const std::function<void(int, int)>* fn = nullptr;
+        int n = 0, pending = 0;
+        uint64_t gen = 0;
+        bool stop = false;
+    };
+    static void loop(State& S, int id) {
         uint64_t seen = 0;
         for (;;) {
             const std::function<void(int, int)>* fn = nullptr;
             int n = 0;
             {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_;
-                if (id < n_) { fn = fn_; n = n_; }
+                std::unique_lock<std::mutex> lk(S.m);
+                S.cv.wait(lk, [&] { return S.stop || S.gen != seen; });
+                if (S.stop) return;
+                seen = S.gen;
+                if (id < S.n) { fn = S.fn; n = S.n; }
             }
             if (fn) {
                 (*fn)(id, n);
-                std::lock_guard<std::mutex> lk(m_);
-                if (--pending_ == 0) done_.notify_one();
+                std::lock_guard<std::mutex> lk(S.m);
+                if (--S.pending == 0) S.done.notify_one();
             }
         }
     }
-    std::mutex m_, region_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> threads_;
-    const std::function<void(int, int)>* fn_ = nullptr;
-    int n_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
+    State* st_ = new State();
+    pid_t pid_ = getpid();
 };
 }  // namespace
 

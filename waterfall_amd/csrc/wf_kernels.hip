@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -4952,6 +4953,10 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     return WF_OK;
 }
 
+// Test aid: every allocating call the library makes (pinned staging ring, streams, events) bumps this counter, so that a
+// test can show that an entry point made none (wf_debug_alloc_count).  The library never allocates device memory.
+std::atomic<int64_t> g_alloc_count{0};
+
 // optional per-kernel timing (bench.py's roofline leg): HIP events recorded on the caller's stream
 // around each kernel of the last wf_fb_logsum / wf_fb_backward call of this thread.
 struct Timing {
@@ -4965,6 +4970,7 @@ thread_local Timing g_tm;
 int tm_record(int i, hipStream_t st) {
     if (!g_tm.on) return WF_OK;
     if (!g_tm.made) {
+        g_alloc_count.fetch_add(1);
         for (auto& e : g_tm.ev) HIP_TRY(hipEventCreate(&e));
         g_tm.made = true;
     }
@@ -5001,6 +5007,7 @@ struct Side {
 thread_local Side g_side[kMaxDevices];
 
 int ring_alloc(Side& s, size_t slot_bytes) {
+    g_alloc_count.fetch_add(1);
     if (s.ring) {
         for (int i = 0; i < kRingSlots; ++i)
             if (s.ring_used[i]) { HIP_TRY(hipEventSynchronize(s.ring_ev[i])); s.ring_used[i] = false; }
@@ -5020,6 +5027,7 @@ int side_get(Side** out, bool create = true) {
     Side& s = g_side[dev];
     if (!s.stream) {
         if (!create) return wf_fail(WF_EINVAL, "wf_init() has not been called by this thread on device %d", dev);
+        g_alloc_count.fetch_add(1);
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
@@ -6058,6 +6066,12 @@ extern "C" int wf_fb_logsum_static(const void* graph_host, const void* graph_dev
         return wf_fail(WF_EUNSUPPORTED, "wf_fb_logsum_static: WF_KEEP_AB / WF_PREZERO (a later wf_fb_backward) need a caller-owned workspace");
     return fb_logsum_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, Tmax, V, seg, B, output_beam,
                           flags, grad_scale, tot, grad, nullptr, 0, stream, true);
+}
+
+extern "C" int wf_debug_alloc_count(int64_t* count) {
+    if (!count) return wf_fail(WF_EINVAL, "null count");
+    *count = g_alloc_count.load();
+    return WF_OK;
 }
 
 extern "C" int wf_static_scratch_bytes(size_t* bytes) {
