@@ -41,7 +41,7 @@ from waterfall_amd import _lib  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 KERNEL_NAMES = {"gather": "gather_lin_small_kernel", "sweep": "sweep_band_kernel", "post": "post_small_kernel",
                 "zero": "sweep_band_kernel (fill workgroups of the same launch)", "check": "rescue_kernel"}
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 STATS_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_bench_cfg3_kernel_stats.txt")
 META_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_meta.json")          # {"kernel_source_sha256": ...} at profiling time
@@ -65,13 +65,36 @@ def profiles_current():
         return False
 
 
+def _pmc_kernel(ks, kernel):
+    """Entry of the PMC summary for one of the step's kernels (matched by the stem of its name: the table-in-arguments
+    variant of the gather kernel carries a suffix)."""
+    name = KERNEL_NAMES.get(kernel, "").split(" ")[0]
+    hit = [v for k, v in ks.items() if name and k.startswith(name.replace("_kernel", ""))]
+    return hit[0] if hit else None
+
+
+def pmc_step_traffic(is_default_workload):
+    """HBM bytes ONE STEP moves according to the committed PMC passes: the sum over the step's kernels (median launch of
+    each), or None without a current measurement."""
+    if not is_default_workload or not os.path.exists(PMC_FILE) or not profiles_current():
+        return None
+    ks = json.load(open(PMC_FILE))["kernels"]
+    tot = 0.0
+    for kernel in ("gather", "sweep", "post", "check"):
+        k = _pmc_kernel(ks, kernel)
+        if k is None:
+            return None
+        tot += k["hbm_bytes_per_launch_fetch_doubled"]
+    return tot
+
+
 def pmc_traffic(kernel, is_default_workload):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read), or None when there is no
     measurement for this workload and kernel source."""
     if not is_default_workload or not os.path.exists(PMC_FILE) or not profiles_current():
         return None
-    k = json.load(open(PMC_FILE))["kernels"].get(KERNEL_NAMES.get(kernel, "").split(" ")[0])
+    k = _pmc_kernel(json.load(open(PMC_FILE))["kernels"], kernel)
     return k["hbm_bytes_per_launch_fetch_doubled"] if k else None
 
 
@@ -286,17 +309,19 @@ def kernel_times(wl, stream, reps=20):
 
     def run():
         lib.wf_timing_enable(1)
-        acc = np.zeros(5)
+        acc = np.zeros(6)
         ms = (C.c_float * 8)()
         for _ in range(reps):
             wl.step(stream)
             _lib.check(lib.wf_timing_read(ms))
-            acc += np.array(list(ms)[:5])
+            acc += np.array(list(ms)[:6])
         lib.wf_timing_enable(0)
-        return dict(zip(("gather", "sweep", "post", "zero", "check"), (acc / reps).tolist()))
+        return dict(zip(("gather", "sweep", "post", "zero", "check", "sweep_device_span"), (acc / reps).tolist()))
 
     kt = run()
+    span = kt.pop("sweep_device_span")
     kt["fill_in_sweep"] = bool(kt["zero"] < 0 and kt["check"] >= 0 and wl.fsa.all_compact())
+    kt["sweep_device_span"] = span
     if kt["zero"] < 0 and kt["check"] >= 0:
         old = os.environ.get("WF_FILL_SIDE_STREAM")
         os.environ["WF_FILL_SIDE_STREAM"] = "1"
@@ -470,7 +495,13 @@ def viterbi_bench(dev, S, B=8, T=500, V=5001, reps=3):
     csum = best_path_checksum(out["scores"].cpu().numpy(), out["arcs"].cpu().numpy())
     return {"ms_per_call": ms, "score_sum": csum[0], "arcs_checksum": csum[1],
             "checked_by": "tests/test_gpu_parity.py::test_cfg5_benched_workload_bit_exact_against_c_oracle (same workload, C oracle)", "us_per_frame": ms * 1e3 / T, "frames_per_s": B * T / (ms * 1e-3),
-            "algorithmic_GBps": B * T * (4 * V + 16 * A + 4 * S) / (ms * 1e-3) / 1e9,
+            # SURVEY 8(d) charges 4V + 16A + 4S per utterance-frame; big_step_shared_kernel reads the arcs ONCE per frame for the 8
+            # utterances of a lane group, so the bytes a frame's launch must move are 16A per GROUP plus, per utterance, the
+            # back-pointers (4S), alpha in and out (2 x 4S) and the K gathered emissions
+            "survey_8d_bytes_GBps": B * T * (4 * V + 16 * A + 4 * S) / (ms * 1e-3) / 1e9,
+            "survey_8d_bytes_GBps_is": "SURVEY 8(d) bytes per utterance-frame / time: NOT a bandwidth (arcs are shared by 8 utterances)",
+            "launch_model_bytes_per_frame": ((B + 7) // 8) * 16 * A + B * (4 * S + 8 * S),
+            "launch_model_GBps": T * (((B + 7) // 8) * 16 * A + B * (4 * S + 8 * S)) / (ms * 1e-3) / 1e9,
             "desc": f"cfg5 Viterbi + back-trace, synthetic TLG-like graph S={S} A={A}, B={B}, T={T}, V={V}, exact search, "
                     "includes the host-side label extraction of wf.best_path"}
 
@@ -516,7 +547,10 @@ def num_den_bench(dev, B=32, T=500, P=5000, L=64, reps=10):
     lp = torch.log_softmax(torch.randn(B, T, V, generator=gen, device=dev) * 3.0, -1).requires_grad_(True)
     seg = torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32)
     out = {}
-    for name in ("two_call", "num_den"):
+    for name in ("two_call", "num_den", "two_call_pruned_beam10"):
+        # (the first two in the "exact" beam mode, as the headline; the third with the drop-in's default: output_beam = 10 honoured)
+        wf.set_output_beam_mode("pruned" if "pruned" in name else "exact")
+
         def step():
             lp.grad = None
             d = wf.DenseFsaVec(lp, seg)
@@ -536,6 +570,7 @@ def num_den_bench(dev, B=32, T=500, P=5000, L=64, reps=10):
         out[name + "_ms_per_step"] = (time.perf_counter() - t0) / reps * 1e3
         out[name + "_loss"] = float(l.detach())
         out[name + "_grad_abs_sum"] = float(lp.grad.abs().sum())
+    wf.set_output_beam_mode(wf.graph.DEFAULT_BEAM_MODE)
     out["desc"] = f"mmictc numerators (L={L}) - denominators (S={2 * (P + 1) + 2}), V={V}, B={B}, T={T}, reduction=sum, loss + backward under autograd"
     out["checked_by"] = "tests/test_gpu_parity.py::test_graphloss_num_den_equals_the_two_call_form"
     return out
@@ -641,6 +676,7 @@ def main():
     if rank == 0:
         kt = kernel_times(wl, stream)
         fill_in_sweep = kt.pop("fill_in_sweep")
+        sweep_span_ms = kt.pop("sweep_device_span")
         kb = wl.kernel_bytes(lin=kt["check"] >= 0)
         dom = max(kt, key=lambda k: kt[k])
         if fill_in_sweep:
@@ -668,6 +704,11 @@ def main():
                                          "(avg_launch_ms); *_rocprof: the same bytes / the kernel's average duration in the "
                                          "committed rocprofv3 summary, null when that summary is of another kernel source",
                            "rocprof_avg_launch_us": rp_us,
+                           # the launch's own duration measured INSIDE the kernel (s_memrealtime, latest workgroup end - earliest
+                           # start): free of the HIP-event latency in avg_launch_ms and of the profiler's inflation of rocprof_*
+                           "in_kernel_launch_us": sweep_span_ms * 1e3 if (dom == "sweep" and sweep_span_ms > 0) else None,
+                           "achieved_in_kernel": kb[dom] / (sweep_span_ms * 1e-3) / 1e9 if (dom == "sweep" and sweep_span_ms > 0) else None,
+                           "frac_in_kernel": kb[dom] / (sweep_span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (dom == "sweep" and sweep_span_ms > 0) else None,
                            "achieved_rocprof": kb[dom] / (rp_us * 1e-6) / 1e9 if rp_us else None,
                            "frac_rocprof": kb[dom] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS if rp_us else None,
                            "profiles_match_kernel_source": profiles_current(),
@@ -688,7 +729,15 @@ def main():
         if fill_in_sweep:
             out["kernels"]["sweep"]["algorithmic_bytes_sweep_alone"] = kb["sweep_alone"]
         out["kernels"]["sweep"]["us_per_frame_step"] = kt["sweep"] * 1e3 / args.frames
+        out["kernels"]["sweep"]["in_kernel_span_ms"] = sweep_span_ms if sweep_span_ms > 0 else None
+        # SURVEY 8(d)'s ALGORITHMIC bytes (4V log_probs row + 4V gradient row + 8S per frame) over the step time: a
+        # figure of merit, NOT moved bytes -- the numerators' gather reads K of the V columns (whole 128-byte lines of them)
         out["path_GBps_survey_8d"] = kb["path_survey_8d"] / (ms_step * 1e-3) / 1e9
+        out["path_GBps_survey_8d_is"] = "algorithmic bytes of SURVEY 8(d) / step time; the bytes actually moved are traffic_GBps"
+        step_traffic = pmc_step_traffic(default_wl)
+        out["traffic_bytes_per_step_pmc"] = step_traffic
+        out["traffic_GBps"] = step_traffic / (ms_step * 1e-3) / 1e9 if step_traffic else None
+        out["traffic_frac_of_hbm_peak"] = step_traffic / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS if step_traffic else None
         if world == 1:
             try:   # the optional tail of the fused all-reduce buffer: its kernel, timed here
                 buf = torch.zeros(3 + wl.V, dtype=torch.float32, device=dev)
@@ -726,6 +775,8 @@ def main():
                     d2 = float(np.median(time_steps(w2, n2, 3, None, stream, fused[:3], min_region_s=0.03)))
                     k2 = kernel_times(w2, stream, reps=5)
                     k2["fill_in_sweep"] = bool(k2["fill_in_sweep"])
+                    if k2["sweep_device_span"] < 0:
+                        k2.pop("sweep_device_span")
                     others[name] = {"frames_per_s": w2.frames / (d2 / n2), "ms_per_step": d2 / n2 * 1e3,
                                     "fallback_utterances": w2.fallbacks(stream),
                                     "arc_updates_per_sec": 2 * w2.arc_updates / (d2 / n2), "kernels_ms": k2,

@@ -303,8 +303,10 @@ int wf_label_grad_sums(const float* grad, int64_t strideB, int64_t strideT, int3
 /* ---- measurement aid (no counterpart in the reference) ------------------------------------------
  * wf_timing_enable(1): the following wf_fb_logsum / wf_fb_backward calls of this host thread record
  * HIP events on the caller's stream around each kernel; wf_timing_read() waits for them and
- * returns ms[5] = {emission gather, alpha/beta sweep, posterior/gradient, gradient zero-fill (runs on
- * a side stream concurrently with the sweep), row check + fallback} kernel times in ms (-1 = not run).
+ * returns ms[6] = {emission gather, alpha/beta sweep, posterior/gradient, gradient zero-fill (runs on
+ * a side stream concurrently with the sweep), row check + fallback} kernel times in ms (-1 = not run), and ms[5] = the
+ * banded sweep launch's own duration measured INSIDE the kernel (s_memrealtime: latest workgroup end - earliest
+ * workgroup start), which carries neither event nor profiler overhead.
  * Used by bench.py for the per-kernel roofline numbers.                                          */
 int wf_timing_enable(int on);
 int wf_timing_read(float* ms);

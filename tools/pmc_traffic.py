@@ -21,7 +21,11 @@ def per_kernel(path, counter):
         if not m or "anonymous namespace)::" not in name or "at::native" in name:
             continue
         out.setdefault(m.group(1), []).append(float(val))
-    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+    # MEDIAN launch, not the mean: one kernel name covers launches that do different work (sweep_band_kernel with and
+    # without the fill workgroups -- bench.py's per-kernel timing leg sends the fill to the side stream for 20 launches;
+    # round 2's mean mixed 114 launches of 353 MB with 20 of 33 MB into "306 MB")
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {k: med(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
 
 
 fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")

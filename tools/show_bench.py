@@ -26,7 +26,10 @@ for line in open(sys.argv[1]):
             print(f"   {k:28s} {v['ms_per_call']:.3f} ms/call ({v['ms_per_call_with_log_total']:.3f} with log total)  exact sweep {v['exact_sweep_ms_per_call']:.3f} ms  x{v['speedup_vs_exact']:.2f}  same path {v['same_path']}")
             continue
         if "ms_per_call" in v:
-            print(f"   {k:28s} {v['frames_per_s']:.4g} f/s  {v['ms_per_call']:.3f} ms/call  {v['us_per_frame']:.1f} us/frame  {v['algorithmic_GBps']:.0f} GB/s (algorithmic)")
+            print(f"   {k:28s} {v['frames_per_s']:.4g} f/s  {v['ms_per_call']:.3f} ms/call  {v['us_per_frame']:.1f} us/frame  {v['launch_model_GBps']:.0f} GB/s (bytes a launch must move)")
+            continue
+        if "ratio_to_exact" in v:
+            print(f"   {k:28s} {v['frames_per_s']:.4g} f/s  {v['ms_per_step']:.4f} ms  (exact {v['exact_ms_per_step']:.4f} ms, x{v['ratio_to_exact']:.2f}; fallbacks {v['fallback_utterances']})")
             continue
         print(f"   {k:28s} {v['frames_per_s']:.4g} f/s  {v['ms_per_step']:.4f} ms  " +
               " ".join(f"{a}={b*1e3:.1f}us" for a, b in v["kernels_ms"].items() if not isinstance(b, bool)))

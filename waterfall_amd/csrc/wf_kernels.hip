@@ -143,6 +143,9 @@ struct SweepArgs {
     // instantiations of sweep_band_kernel), one row per (utterance, frame) in WF_U_ROW0 order
     unsigned long long* bmask;
     int64_t bmask_rows;
+    // measurement aid (wf_timing_enable): {earliest start, latest end} over the workgroups of a sweep_band_kernel launch on
+    // the 100 MHz constant clock (s_memrealtime) -- the launch's own duration on the device, free of event / profiler overhead
+    unsigned long long* tspan;
     int ablate;    // measurement aids, never set by the product path: bit 8 (WF_SWEEP_PROFILE=1) workgroup 0 prints its cycles per
                    // frame step; sweep_kernel, WF_SWEEP_ABLATE: 16 no register copy of streamed arcs, 32 no row stores, 64 no heavy
                    // states, 128 no light states (32-128 give wrong results: timing only); sweep_hub_kernel (tools/abl_hub.sh):
@@ -2006,6 +2009,7 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
     static_assert(!GEN || (R == 1 && BW == 1 && MM == 1), "general-graph mode: one state per lane");
     extern __shared__ __align__(16) unsigned char smem[];
     const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+    if (p.tspan && threadIdx.x == 0) atomicMin(p.tspan, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     // LDS: staged emission rows [2][C][kBandKP] x 8 B | 2 x 64 exponent words | 2 shift words
     int* ebuf = (int*)(smem + 2 * kBandPBytes);
     int* shw = ebuf + 128;
@@ -2019,6 +2023,10 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         for (size_t i = (size_t)(blockIdx.x - p.nsweep) * 128 + tid; i < p.zn4; i += stride)
             __builtin_nontemporal_store(z, (v4f*)p.zp + i);
         if ((int)blockIdx.x == p.nsweep && tid < p.zntail) p.ztail[tid] = 0.f;
+        if (p.tspan) {
+            __builtin_amdgcn_s_waitcnt(0);   // this workgroup's stores have been acknowledged
+            if (tid == 0) atomicMax(p.tspan + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        }
         return;
     }
     const int u = blockIdx.x >> 1, dir = blockIdx.x & 1;
@@ -2345,6 +2353,10 @@ __global__ void __launch_bounds__(128) sweep_band_kernel(SweepArgs p) {
         }
         if ((p.ablate & 8) && blockIdx.x == 0 && lane == 0)
             printf("stager (even chunks): barrier-wait=%.0f stage=%.0f issue=%.0f cycles\n", 2.0 * t_bar / max(nc, 1), 2.0 * t_stage / max(nc, 1), 2.0 * t_issue / max(nc, 1));
+    }
+    if (p.tspan && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);   // the chain wave's row stores have been acknowledged
+        atomicMax(p.tspan + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -4959,7 +4971,10 @@ std::atomic<int64_t> g_alloc_count{0};
 
 // optional per-kernel timing (bench.py's roofline leg): HIP events recorded on the caller's stream
 // around each kernel of the last wf_fb_logsum / wf_fb_backward call of this thread.
+static __device__ unsigned long long g_tspan_dev[2];   // SweepArgs::tspan (timing runs only)
 struct Timing {
+    unsigned long long* tspan = nullptr;   // device address of g_tspan_dev on the device of the last timed call
+    bool have_span = false;
     bool on = false;
     hipEvent_t ev[8] = {};   // t0 | gather | sweep | (post t0) | post | zero t0 | zero t1 | check + fallback
     bool made = false;
@@ -5851,6 +5866,15 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     const bool postcheck = P.lin && grad && !(flags & WF_PREZERO) && !hk().no_post_check && !accum &&
                            (P.hub || ((overlap || !P.any_compact) && post_small_fits(P)));
     ForkGuard guard(st);   // every return below first makes `st` wait for the side stream
+    g_tm.have_span = false;
+    if (g_tm.on && P.lin && !P.hub && band_config(P).ok) {   // (reset in front of the timed intervals)
+        void* sp = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&sp, HIP_SYMBOL(g_tspan_dev)));
+        g_tm.tspan = (unsigned long long*)sp;
+        HIP_TRY(hipMemsetAsync(sp, 0xff, 8, st));
+        HIP_TRY(hipMemsetAsync((char*)sp + 8, 0, 8, st));
+        g_tm.have_span = true;
+    }
     if ((rc = tm_record(0, st))) return rc;
     rc = launch_gather(P, graph_dev, ws, log_probs, strideB, strideT, st, tab, need_ab || pruned);
     if (rc) return rc;
@@ -5934,6 +5958,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
             if ((rc = launch_trop_band(bs, ta, bm, B, P.Tlong, st))) return rc;
             a.bmask = (unsigned long long*)(ws + P.off_bmask); a.bmask_rows = P.n_rows;
         }
+        if (g_tm.have_span) a.tspan = g_tm.tspan;
         rc = P.hub ? launch_sweep_hub(P, a, B, st) : bs.ok ? launch_sweep_band(bs, a, B, st, nfill, P.pruned_fast) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
@@ -6276,11 +6301,12 @@ extern "C" int wf_grad_scale(const void* graph_host, const void* graph_dev, cons
 
 extern "C" int wf_timing_enable(int on) { g_tm.on = on != 0; g_tm.have_fwd = g_tm.have_post = g_tm.have_zero = false; return WF_OK; }
 
-// ms[0..4] = gather, sweep, post, zero-fill, check + fallback kernel time of the last timed call(s);
+// ms[0..4] = gather, sweep, post, zero-fill, check + fallback kernel time of the last timed call(s); ms[5] = the banded
+// sweep launch's own duration on the device (in-kernel s_memrealtime: latest workgroup end - earliest start);
 // -1 = not measured.  Synchronises on the recorded events (a measurement aid, not part of the hot path).
 extern "C" int wf_timing_read(float* ms) {
     if (!ms) return wf_fail(WF_EINVAL, "wf_timing_read: null");
-    ms[0] = ms[1] = ms[2] = ms[3] = ms[4] = -1.f;
+    ms[0] = ms[1] = ms[2] = ms[3] = ms[4] = ms[5] = -1.f;
     if (g_tm.have_check) {
         HIP_TRY(hipEventSynchronize(g_tm.ev[7]));
         HIP_TRY(hipEventElapsedTime(&ms[4], g_tm.ev[g_tm.check_from], g_tm.ev[7]));
@@ -6297,6 +6323,11 @@ extern "C" int wf_timing_read(float* ms) {
     if (g_tm.have_zero) {
         HIP_TRY(hipEventSynchronize(g_tm.ev[6]));
         HIP_TRY(hipEventElapsedTime(&ms[3], g_tm.ev[5], g_tm.ev[6]));
+    }
+    if (g_tm.have_span && g_tm.have_fwd) {
+        unsigned long long sp[2] = {0, 0};
+        HIP_TRY(hipMemcpy(sp, g_tm.tspan, sizeof(sp), hipMemcpyDeviceToHost));   // (the events above were waited for)
+        if (sp[1] > sp[0]) ms[5] = (float)((double)(sp[1] - sp[0]) * 1e-5);       // 100 MHz ticks -> ms
     }
     return WF_OK;
 }
