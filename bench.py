@@ -45,7 +45,7 @@ PROFILE_TAG = "r03"
 PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 STATS_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_bench_cfg3_kernel_stats.txt")
 META_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_meta.json")          # {"kernel_source_sha256": ...} at profiling time
-KERNEL_SOURCES = [os.path.join(ROOT, "waterfall_amd", "csrc", f) for f in ("wf_kernels.hip", "wf_internal.h")]
+KERNEL_SOURCES = [os.path.join(ROOT, "waterfall_amd", "csrc", f) for f in ("wf_kernels.hip", "wf_internal.h")]   # (the profiled kernels' sources)
 
 
 def kernel_source_hash():

@@ -159,6 +159,32 @@ int wf_numerator_compile(const int32_t* topo_arcs, const int32_t* topo_aux, int3
                          int32_t* out_arc_off, int32_t* out_num_states,
                          void* blob, size_t blob_bytes, size_t* blob_bytes_needed, int32_t nthreads);
 
+/* ---- the numerator graph compiler ON THE DEVICE (models.py:263-270 / datapipe.py:233-256 run on every
+ * training step) -----------------------------------------------------------------------------------------------------
+ * Same graphs and the same prepared tables as wf_numerator_compile, built by one wavefront per utterance from the flat
+ * transcripts: nothing but the transcripts crosses PCIe and the host does no graph work.
+ * wf_topo_device_build: the topology tables the kernel reads (arc arrays, the wf_topo_index_build index, the factored-CTC
+ *   tables, per phone the states its arcs enter), once per topology, into a host buffer the caller uploads.  out == NULL:
+ *   only *words_needed.
+ * wf_numerator_compile_device_bytes: sizes of the caller-allocated DEVICE buffers for a batch with these transcript lengths.
+ * wf_numerator_compile_device: two launches on `stream`.  topo_tab: the HOST copy of the table (read for sizes only).
+ *   phones_dev / phones_off_dev: the transcripts on the device; phones_off: the same offsets on the host.  Outputs, all on
+ *   the device: blob_dev (the prepared graph vector: header, per-FSA info words, tables; every graph at the start of a
+ *   capacity-sized region), arcs_dev [.][4] + aux_dev (the FsaVec arrays, compact), meta_dev int32 [3B + 1] = arc offsets
+ *   [B + 1] | states [B] | status [B].  status != 0 (transcript beyond 256 positions, more than 257 states / 1024 arcs, a
+ *   phone out of range, ...): that utterance was not compiled, the blob's magic word is 0 and the caller compiles the batch
+ *   on the host.  To plan the compute calls the caller copies the first 8 + 64 B words (rounded up to 4) of blob_dev (header + info
+ *   words) to the host: that prefix is all the host side of wf_fb_logsum / wf_viterbi / wf_search reads of a blob.     */
+int wf_topo_device_build(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t topo_num_arcs, int32_t topo_num_states,
+                         const int32_t* index, int64_t index_words, int32_t ctc_cross, const int32_t* phone_state,
+                         const int32_t* phone_token, int32_t num_phones, int32_t* out, int64_t out_words, int64_t* words_needed);
+int wf_numerator_compile_device_bytes(const int32_t* topo_tab, const int32_t* phones_off, int32_t B, size_t* blob_bytes,
+                                      int64_t* arc_capacity, size_t* work_bytes);
+int wf_numerator_compile_device(const int32_t* topo_tab, const void* topo_tab_dev, const int32_t* phones_dev,
+                                const int32_t* phones_off_dev, const int32_t* phones_off, int32_t B, void* blob_dev,
+                                size_t blob_bytes, int32_t* arcs_dev, int32_t* aux_dev, int64_t arc_capacity,
+                                int32_t* meta_dev, void* work_dev, size_t work_bytes, void* stream);
+
 /* The same for ARBITRARY epsilon-free right-hand graphs (one per utterance), e.g. the phone-level graph of a word
  * sequence under a lexicon with alternative pronunciations and optional silence (datapipe.py:244-254: L_inv o words,
  * inverted, epsilons removed, epsilon self-loops added, then k2.compose(topo, ., treat_epsilons_specially=False)).

@@ -6,8 +6,8 @@
   super-final state (the last state id).
 * ``compose_topo_transcript``: ``k2.compose(topo, remove_epsilon_and_add_self_loops(linear_fsa(t)),
   treat_epsilons_specially=False)`` as used by ``waterfall/models.py:263-270``; rule written in
-  SURVEY.md 8(0) "Composition rule".  State numbering = BFS discovery order (k2's own numbering is
-  parity unpinned).
+  SURVEY.md 8(0) "Composition rule".  States are discovered breadth first and numbered position-major
+  (k2's own numbering is parity unpinned).
 * ``ctc_trans_transform``: ``utils/make_transition_mat.py:27-57`` and
   ``utils/make_transform_mat.py:10-36`` (those modules import kaldiio and cannot be imported).
 * ``graph_to_trans_transform``: encodes any graph as the (trans, transform) pair that
@@ -87,7 +87,16 @@ def compose_topo_transcript(topo, phones):
     for s, w in fin:
         arcs.append((s, sf, -1, w))
         aux.append(-1)
-    return make_graph(arcs, sf + 1, aux)
+    return make_graph(_position_major(arcs, order, sf), sf + 1, aux)
+
+
+def _position_major(arcs, order, sf):
+    """States are discovered breadth first but NUMBERED by (right-hand state, topology state) -- position-major for a
+    linear transcript, the numbering of the product's compilers (wf_graph.cpp renumber_position_major; k2's own numbering
+    in compose is parity unpinned).  Arcs keep their order within a state (make_graph's stable sort by source)."""
+    new = {old: i for i, old in enumerate(sorted(range(len(order)), key=lambda j: (order[j][1], order[j][0])))}
+    new[sf] = sf
+    return [(new[s], new[d], lab, w) for s, d, lab, w in arcs]
 
 
 def compose_topo_fsa(topo, b):
@@ -134,7 +143,7 @@ def compose_topo_fsa(topo, b):
     for s, w in fin:
         arcs.append((s, sf, -1, float(w)))
         aux.append(-1)
-    return make_graph(arcs, sf + 1, aux)
+    return make_graph(_position_major(arcs, order, sf), sf + 1, aux)
 
 
 FMIN = np.finfo(np.float32).min

@@ -210,7 +210,149 @@ def _compose_graphs(topo, b):
     return Fsa(oa[:n], ox[:n], arc_off, ns[:B])
 
 
-def compile_ctc_k2_graphs(topo, targets):
-    """The whole ``ctc_k2`` numerator chain of models.py:263-270 in one call."""
+def compile_ctc_k2_graphs(topo, targets, device=None, stream=None):
+    """The whole ``ctc_k2`` numerator chain of models.py:263-270 in one call.  device = a CUDA device: the graphs are
+    built ON that device (compile_ctc_k2_graphs_device below); otherwise on the host."""
+    if device is not None and str(device) != "cpu":
+        return compile_ctc_k2_graphs_device(topo, targets, device, stream)
     return compose(topo, arc_sort(remove_epsilon_and_add_self_loops(linear_fsa(targets))),
                    treat_epsilons_specially=False)
+
+
+# ---- the numerator compiler on the device (wf_compile.hip; SURVEY.md 8(f) rank 1) ---------------------------------------
+
+_COMPILE_STREAMS = {}
+
+
+def _compile_stream(device):
+    import torch
+    s = _COMPILE_STREAMS.get(device.index)
+    if s is None:
+        s = _COMPILE_STREAMS[device.index] = torch.cuda.Stream(device)
+    return s
+
+
+def _topo_device_table(topo, device):
+    """(host copy, device copy) of wf_topo_device_build's table for a topology; cached on the object per device."""
+    import torch
+    tab = _topo_tables(topo)
+    cache = tab.setdefault("device_tables", {})
+    key = str(device)
+    if key not in cache:
+        lib = _lib.lib()
+        ps, pt = tab["phone_state"], tab["phone_token"]
+        args = (tab["arcs"].ctypes.data, tab["aux"].ctypes.data, tab["arcs"].shape[0], tab["num_states"], tab["index"].ctypes.data,
+                tab["index"].size, tab["ctc_cross"], ps.ctypes.data if ps is not None else None,
+                pt.ctypes.data if pt is not None else None, ps.size if ps is not None else 0)
+        n = C.c_int64(0)
+        _lib.check(lib.wf_topo_device_build(*args, None, 0, C.byref(n)))
+        host = np.empty(n.value, dtype=np.int32)
+        _lib.check(lib.wf_topo_device_build(*args, host.ctypes.data, host.size, C.byref(n)))
+        cache[key] = (host, torch.from_numpy(host).to(device))
+    return cache[key]
+
+
+class _DeviceCompileJob:
+    """One batch in flight through numerator_compile_kernel: the device buffers, the pinned copies of what the host needs
+    to plan the compute calls (blob header + per-FSA info words, arc offsets, states, status) and the event behind them."""
+
+    def __init__(self, topo, lin, device, stream):
+        import torch
+        lib = _lib.lib()
+        self.topo, self.lin, self.device = topo, lin, device
+        self.B = B = len(lin)
+        host_tab, dev_tab = _topo_device_table(topo, device)
+        off = lin.off
+        nb, cap, nw = C.c_size_t(0), C.c_int64(0), C.c_size_t(0)
+        _lib.check(lib.wf_numerator_compile_device_bytes(host_tab.ctypes.data, off.ctypes.data, B, C.byref(nb), C.byref(cap), C.byref(nw)))
+        self.stream = stream if stream is not None else _compile_stream(device)
+        nhdr = (8 + 64 * B + 3) // 4 * 4
+        with torch.cuda.device(device), torch.cuda.stream(self.stream):
+            # (allocated under the compile stream: the caching allocator orders their reuse after this stream's work)
+            flat = lin.flat if lin.flat.size else np.zeros(1, dtype=np.int32)
+            host_in = torch.empty(flat.size + B + 1, dtype=torch.int32, pin_memory=True)
+            host_in[:flat.size] = torch.from_numpy(flat)
+            host_in[flat.size:] = torch.from_numpy(off)
+            dev_in = host_in.to(device, non_blocking=True)
+            self.blob = torch.empty(nb.value // 4, dtype=torch.int32, device=device)
+            self.arcs_dev = torch.empty((max(cap.value, 1), 4), dtype=torch.int32, device=device)
+            self.aux_dev = torch.empty(max(cap.value, 1), dtype=torch.int32, device=device)
+            self.meta_dev = torch.empty(3 * B + 1, dtype=torch.int32, device=device)
+            work = torch.empty(nw.value, dtype=torch.uint8, device=device)
+            _lib.check(lib.wf_numerator_compile_device(host_tab.ctypes.data, C.c_void_p(dev_tab.data_ptr()), C.c_void_p(dev_in.data_ptr()),
+                                                       C.c_void_p(dev_in[flat.size:].data_ptr()), off.ctypes.data, B,
+                                                       C.c_void_p(self.blob.data_ptr()), nb.value, C.c_void_p(self.arcs_dev.data_ptr()),
+                                                       C.c_void_p(self.aux_dev.data_ptr()), cap.value, C.c_void_p(self.meta_dev.data_ptr()),
+                                                       C.c_void_p(work.data_ptr()), nw.value, C.c_void_p(self.stream.cuda_stream)))
+            self.hdr_pin = torch.empty(nhdr, dtype=torch.int32, pin_memory=True)
+            self.meta_pin = torch.empty(3 * B + 1, dtype=torch.int32, pin_memory=True)
+            self.hdr_pin.copy_(self.blob[:nhdr], non_blocking=True)
+            self.meta_pin.copy_(self.meta_dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+            self._keep = (host_in, dev_in, work, dev_tab)
+        self.joined = set()
+
+    def finish(self, fsa):
+        """Waits for the header; adopts the device blob, or -- when an utterance was beyond the kernel's limits -- compiles
+        the batch on the host instead."""
+        self.event.synchronize()
+        hdr = self.hdr_pin.numpy()
+        if int(hdr[0]) == 0:        # the blob's magic word is 0: some status != 0
+            host = compose(self.topo, self.lin)
+            fsa._pending = None
+            fsa.arcs, fsa.aux_labels = host.arcs, host.aux_labels
+            fsa.fsa_arc_offsets, fsa.fsa_num_states = host.fsa_arc_offsets, host.fsa_num_states
+            fsa._blob_host, fsa._blob_pin = host._blob_host, host._blob_pin
+            fsa.compiled_on = "host (device compiler status %s)" % sorted(set(int(x) for x in self.meta_pin.numpy()[2 * self.B + 1:]) - {0})
+            return
+        fsa._blob_host = hdr
+        fsa._blob_dev[str(self.device)] = self.blob
+
+    def join_stream(self, device):
+        import torch
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream not in self.joined and cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_event(self.event)
+            self.blob.record_stream(cur)
+            self.joined.add(cur.cuda_stream)
+
+    def fetch_arrays(self, fsa):
+        if fsa._blob_host is None:
+            self.finish(fsa)
+            if fsa._pending is None:
+                return
+        meta = self.meta_pin.numpy()
+        B = self.B
+        off = meta[:B + 1].copy()
+        n = int(off[B])
+        fsa.__dict__["_fsa_arc_offsets"] = off
+        fsa.__dict__["_fsa_num_states"] = meta[B + 1:2 * B + 1].copy()
+        fsa.__dict__["_arcs"] = self.arcs_dev[:n].cpu().numpy()
+        fsa.__dict__["_aux_labels"] = self.aux_dev[:n].cpu().numpy()
+
+
+def compile_ctc_k2_graphs_device(topo, targets, device, stream=None):
+    """compile_ctc_k2_graphs on the DEVICE: the transcripts are uploaded (one small asynchronous copy) and
+    numerator_compile_kernel builds the graphs and their prepared tables; the host does no graph work.  Returns at once; the
+    Fsa waits for the kernel's header (a few hundred bytes per utterance, copied back asynchronously) only when a compute
+    call plans with it, so a training loop that compiles step i + 1's graphs before it runs step i's loss hides the
+    compiler behind the loss kernels (the compile kernels run on a stream of their own).  Batches the kernel cannot take
+    (WF_NC_* limits in csrc/wf_internal.h) are compiled on the host, transparently."""
+    import torch
+    device = torch.device(device)
+    lin = arc_sort(remove_epsilon_and_add_self_loops(linear_fsa(targets)))
+    if len(lin) == 0:
+        raise ValueError("compose: empty batch")
+    fsa = Fsa.__new__(Fsa)
+    fsa._pending = None
+    fsa.utt2fsa = None
+    fsa.device = device
+    fsa._blob_host = None
+    fsa._blob_pin = None
+    fsa._blob_dev = {}
+    fsa.compiled_on = "device"
+    for name in ("_arcs", "_aux_labels", "_fsa_arc_offsets", "_fsa_num_states"):
+        fsa.__dict__[name] = None
+    fsa._pending = _DeviceCompileJob(topo, lin, device, stream)
+    return fsa

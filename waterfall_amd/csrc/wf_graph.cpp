@@ -41,25 +41,8 @@ int wf_fail(int code, const char* fmt, ...) {
 
 namespace {
 
-inline size_t pad4(size_t w) { return (w + 3) & ~size_t(3); }
-
-// Upper bound of the words FSA g takes in the blob, from its arc and state counts alone (O(1): no pass over the arcs).
-// K <= 2A + 1: compact columns K <= A; direct columns K = max_label + 1 <= 2 * (#distinct labels).
-inline size_t fsa_words_bound(size_t S, size_t A) {
-    const size_t K = 2 * A + 1;
-    size_t w = 0;
-    w += pad4(S + 1) + 4 * pad4(A);          // in_off, in_src, in_col, in_w, in_arc
-    w += pad4(S + 1) + 4 * pad4(A) + pad4(4 * A);   // out_off, out_dst, out_col, out_w, out_arc, out_rec
-    w += pad4(K + 1) + 4 * pad4(A);          // lab_off, lab_src, lab_dst, lab_w, lab_col
-    w += pad4(K);                            // labels
-    w += 3 * pad4(A);                        // fin_src, fin_w, fin_arc (NF <= A)
-    w += 2 * pad4(S);                        // heavy_in, heavy_out
-    w += 2 * pad4(S) + pad4(A);              // finb_log, finb_max, arc_src
-    if (S - 1 <= 64 * WF_BAND_MAX_R)         // banded form is only built for graphs one wavefront can hold
-        w += pad4(S) + 2 * pad4(S * (WF_BAND_MAX_BW + 1) * WF_BAND_MAX_M * 2);
-    w += pad4(WF_HUB_MAX_NC) + pad4((WF_HUB_MAX_G + 1) * (WF_HUB_MAX_G + 1) * WF_HUB_MAX_NC) + pad4(A);   // hub form
-    return w;
-}
+inline size_t pad4(size_t w) { return wf_pad4(w); }
+inline size_t fsa_words_bound(size_t S, size_t A) { return wf_fsa_words_bound(S, A); }   // (wf_internal.h: shared with the device compiler)
 
 // Scratch reused across the FSAs of a call and across calls of a host thread: no heap traffic per graph.
 struct PrepScratch {
@@ -70,7 +53,12 @@ struct PrepScratch {
 thread_local PrepScratch g_prep;
 
 // Builds FSA g's tables at blob word `cur` (advanced past them).  I: its info words.
-int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& cur, size_t limit, int* out_maxlab) {
+// pos_hint (nullable): per non-final state its layer in a layered graph whose states are numbered layer by layer -- the
+// transcript position of a topo o transcript product (wf_numerator_compile).  The banded order is then "by layer, inside a
+// layer by longest path over the layer's own arcs, then by state id": an order every layer can compute for itself (the
+// device compiler does), where the general Kahn order below needs a traversal of the whole graph.
+int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& cur, size_t limit, int* out_maxlab,
+                const int32_t* pos_hint = nullptr) {
     PrepScratch& X = g_prep;
     const int a0 = gh->fsa_arc_offsets[g], a1 = gh->fsa_arc_offsets[g + 1];
     const int S = gh->fsa_num_states[g];
@@ -289,6 +277,35 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
         if (Sn >= 1 && Sn <= 64 * WF_BAND_MAX_R) {
             X.indeg.assign(Sn, 0); X.order.clear(); X.pos.resize(std::max(std::max(S, K) + 1, Sn));
             int32_t* pos = X.pos.data();
+            if (pos_hint) {
+                // layer by layer; X.indeg holds a state's longest-path depth inside its layer
+                bool ok = true;
+                for (int s0 = 0; s0 < Sn && ok;) {
+                    int s1 = s0 + 1;
+                    while (s1 < Sn && pos_hint[s1] == pos_hint[s0]) ++s1;
+                    const int n = s1 - s0;
+                    bool changed = true;
+                    for (int round = 0; round <= n && changed; ++round) {
+                        changed = false;
+                        for (int s2 = s0; s2 < s1; ++s2)
+                            for (int e = ooff[s2]; e < ooff[s2 + 1]; ++e) {
+                                const int d = odst[e];
+                                if (d == s2 || d < s0 || d >= s1) continue;
+                                if (X.indeg[d] < X.indeg[s2] + 1) { X.indeg[d] = X.indeg[s2] + 1; changed = true; }
+                            }
+                    }
+                    if (changed) { ok = false; break; }   // a cycle inside the layer besides self-loops: no banded order
+                    for (int dep = 0; dep < n; ++dep)
+                        for (int s2 = s0; s2 < s1; ++s2)
+                            if (X.indeg[s2] == dep) { pos[s2] = (int)X.order.size(); X.order.push_back(s2); }
+                    s0 = s1;
+                }
+                if (ok)   // arcs must not run backwards across layers (they do not in a product with a linear transcript)
+                    for (int s2 = 0; s2 < Sn && ok; ++s2)
+                        for (int e = ooff[s2]; e < ooff[s2 + 1]; ++e)
+                            if (pos_hint[odst[e]] < pos_hint[s2]) { ok = false; break; }
+                if (!ok) X.order.clear();
+            } else {
             for (int s2 = 0; s2 < Sn; ++s2)
                 for (int e = ooff[s2]; e < ooff[s2 + 1]; ++e)
                     if (odst[e] != s2) X.indeg[odst[e]]++;
@@ -300,6 +317,7 @@ int prepare_one(const wf_graph_host* gh, int g, int32_t* B, int32_t* I, size_t& 
                 pos[s2] = (int)X.order.size(); X.order.push_back(s2);
                 for (int e = ooff[s2]; e < ooff[s2 + 1]; ++e)
                     if (odst[e] != s2 && --X.indeg[odst[e]] == 0) X.qbuf[qt++] = odst[e];
+            }
             }
             if ((int)X.order.size() == Sn) {
                 int bw = 0;
@@ -475,81 +493,6 @@ extern "C" int wf_graph_prepare(const wf_graph_host* gh, void* blob_host, size_t
     return WF_OK;
 }
 
-// compose(topo, linear(phones) with epsilon self-loops), treat_epsilons_specially=False.
-// Product states (q, i) are numbered in BFS discovery order from (0, 0); arcs are emitted grouped
-// by source state in the topology's arc order; the super-final state is last.
-extern "C" int wf_compose_linear(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA,
-                                 int32_t nS, const int32_t* phones, int32_t L, int32_t* out_arcs,
-                                 int32_t* out_aux, int32_t* out_num_arcs, int32_t* out_num_states,
-                                 int32_t cap) {
-    if (!topo_arcs || !topo_aux || nA < 1 || nS < 2 || L < 0 || (!phones && L > 0) || !out_num_arcs || !out_num_states)
-        return wf_fail(WF_EINVAL, "wf_compose_linear: bad argument");
-    std::vector<int> off(nS + 1, 0);
-    for (int a = 0; a < nA; ++a) {
-        int s = topo_arcs[4 * a];
-        if (s < 0 || s >= nS || topo_arcs[4 * a + 1] < 0 || topo_arcs[4 * a + 1] >= nS)
-            return wf_fail(WF_ERANGE, "wf_compose_linear: topo arc %d state out of range", a);
-        if (a && s < topo_arcs[4 * (a - 1)]) return wf_fail(WF_EINVAL, "wf_compose_linear: topo arcs must be sorted by source state");
-        off[s + 1]++;
-    }
-    for (int s = 0; s < nS; ++s) off[s + 1] += off[s];
-    // reachable product states are few (about 3L) next to nS*(L+1): hash map, not a dense table
-    std::unordered_map<int64_t, int32_t> id;
-    id.reserve(8 * (size_t)(L + 2));
-    std::vector<int64_t> order;
-    order.reserve(8 * (size_t)(L + 2));
-    auto key = [&](int q, int i) { return (int64_t)q * (L + 1) + i; };
-    id.emplace(key(0, 0), 0);
-    order.push_back(key(0, 0));
-    std::vector<int32_t> arcs, aux, fin;
-    for (size_t head = 0; head < order.size(); ++head) {
-        int q = (int)(order[head] / (L + 1)), i = (int)(order[head] % (L + 1));
-        for (int a = off[q]; a < off[q + 1]; ++a) {
-            const int32_t* r = topo_arcs + 4 * (size_t)a;
-            int ph = topo_aux[a];
-            if (r[2] < 0) {
-                if (i == L) { fin.push_back((int32_t)head); fin.push_back(r[3]); }
-                continue;
-            }
-            int ni;
-            if (ph == 0) ni = i;
-            else if (i < L && ph == phones[i]) ni = i + 1;
-            else continue;
-            int64_t k = key(r[1], ni);
-            auto it = id.find(k);
-            int32_t nid;
-            if (it == id.end()) { nid = (int32_t)order.size(); id.emplace(k, nid); order.push_back(k); }
-            else nid = it->second;
-            arcs.push_back((int32_t)head); arcs.push_back(nid); arcs.push_back(r[2]); arcs.push_back(r[3]);
-            aux.push_back(ph);
-        }
-    }
-    const int sf = (int)order.size();
-    // final arcs are appended after all emitting arcs but must stay grouped by source state:
-    // merge them in at the end of their source state's run.
-    const int nE = (int)aux.size(), nF = (int)fin.size() / 2;
-    *out_num_arcs = nE + nF;
-    *out_num_states = sf + 1;
-    if (!out_arcs) return WF_OK;
-    if (cap < nE + nF || !out_aux) return wf_fail(WF_ENOSPC, "wf_compose_linear: arc capacity %d < %d", cap, nE + nF);
-    int w = 0, f = 0, e = 0;
-    while (e < nE || f < nF) {
-        int se = e < nE ? arcs[4 * e] : INT32_MAX;
-        int sfn = f < nF ? fin[2 * f] : INT32_MAX;
-        if (se <= sfn) {
-            memcpy(out_arcs + 4 * (size_t)w, &arcs[4 * (size_t)e], 16);
-            out_aux[w] = aux[e];
-            ++e;
-        } else {
-            out_arcs[4 * w] = fin[2 * f]; out_arcs[4 * w + 1] = sf; out_arcs[4 * w + 2] = -1; out_arcs[4 * w + 3] = fin[2 * f + 1];
-            out_aux[w] = -1;
-            ++f;
-        }
-        ++w;
-    }
-    return WF_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // Batched numerator-graph compiler: the product of wf_compose_linear for a whole
 // batch in one call, against a topology indexed once by (source state, phone).  A product state (q, i) then
@@ -639,6 +582,73 @@ extern "C" int wf_topo_index_build(const int32_t* topo_arcs, const int32_t* topo
     return WF_OK;
 }
 
+// Topology tables of the DEVICE numerator compiler (wf_compile.hip numerator_compile_kernel; layout: wf_internal.h
+// WF_T_*): the arc arrays, the (state, phone) index above, the factored-CTC tables, and per phone the distinct states its
+// arcs enter -- what a transcript position needs to list the topology states that can be alive there without knowing
+// the positions before it.  Built once per topology on the host, uploaded once.  out == NULL: only *words_needed.
+extern "C" int wf_topo_device_build(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA, int32_t nS,
+                                    const int32_t* index, int64_t index_words, int32_t ctc_cross, const int32_t* phone_state,
+                                    const int32_t* phone_token, int32_t num_phones, int32_t* out, int64_t out_words,
+                                    int64_t* words_needed) {
+    if (!topo_arcs || !topo_aux || !index || nA < 1 || nS < 2 || index_words < 1 || !words_needed)
+        return wf_fail(WF_EINVAL, "wf_topo_device_build: bad argument");
+    if (ctc_cross && (!phone_state || !phone_token || num_phones < 1))
+        return wf_fail(WF_EINVAL, "wf_topo_device_build: ctc_cross needs the phone -> state / token tables");
+    const int maxph = topo_max_phone(topo_arcs, topo_aux, nA);
+    const int nph = std::max(maxph, ctc_cross ? num_phones - 1 : 0);
+    std::vector<std::vector<int32_t>> dsts((size_t)nph + 1);
+    for (int a = 0; a < nA; ++a) {
+        const int32_t* r = topo_arcs + 4 * (size_t)a;
+        if (r[2] >= 0 && topo_aux[a] > 0) dsts[topo_aux[a]].push_back(r[1]);
+    }
+    if (ctc_cross)
+        for (int p = 1; p < num_phones; ++p) if (phone_state[p] > 0) dsts[p].push_back(phone_state[p]);
+    size_t npd = 0;
+    for (auto& v : dsts) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); npd += v.size(); }
+    const int32_t* soff = index;
+    const int32_t* key = index + nS + 1 + nA;
+    const int32_t* f1s = key + nA;
+    const int32_t* z1s = f1s + nS;
+    int maxd = 1;
+    for (int q = 0; q < nS; ++q) {
+        int run = 0, best = 0;
+        for (int x = z1s[q]; x < soff[q + 1]; ++x) { run = (x > z1s[q] && key[x] == key[x - 1]) ? run + 1 : 1; best = std::max(best, run); }
+        maxd = std::max(maxd, z1s[q] - f1s[q] + best + (ctc_cross ? 1 : 0));
+    }
+    const int npt = ctc_cross ? num_phones : 0;
+    size_t o = WF_T_HDR;
+    const size_t o_arcs = o; o += 4 * (size_t)nA;
+    const size_t o_aux = o; o += (size_t)nA;
+    const size_t o_index = o; o += (size_t)index_words;
+    const size_t o_ps = o; o += (size_t)npt;
+    const size_t o_pt = o; o += (size_t)npt;
+    const size_t o_pdoff = o; o += (size_t)nph + 2;
+    const size_t o_pdst = o; o += npd;
+    *words_needed = (int64_t)o;
+    if (o >= (size_t)1 << 31) return wf_fail(WF_EUNSUPPORTED, "wf_topo_device_build: table exceeds 2^31 words");
+    if (!out) return WF_OK;
+    if (out_words < (int64_t)o) return wf_fail(WF_ENOSPC, "wf_topo_device_build: %lld words given, %zu needed", (long long)out_words, o);
+    memset(out, 0, sizeof(int32_t) * WF_T_HDR);
+    out[WF_T_MAGIC] = WF_TOPO_MAGIC; out[WF_T_NA] = nA; out[WF_T_NS] = nS; out[WF_T_CROSS] = ctc_cross ? 1 : 0;
+    out[WF_T_NPH] = nph; out[WF_T_MAXPH] = maxph; out[WF_T_OARCS] = (int32_t)o_arcs; out[WF_T_OAUX] = (int32_t)o_aux;
+    out[WF_T_OINDEX] = (int32_t)o_index; out[WF_T_OPSTATE] = (int32_t)o_ps; out[WF_T_OPTOKEN] = (int32_t)o_pt;
+    out[WF_T_OPDOFF] = (int32_t)o_pdoff; out[WF_T_OPDST] = (int32_t)o_pdst; out[WF_T_MAXD] = maxd; out[WF_T_WORDS] = (int32_t)o;
+    out[WF_T_NUMPH] = npt;
+    memcpy(out + o_arcs, topo_arcs, sizeof(int32_t) * 4 * (size_t)nA);
+    memcpy(out + o_aux, topo_aux, sizeof(int32_t) * (size_t)nA);
+    memcpy(out + o_index, index, sizeof(int32_t) * (size_t)index_words);
+    if (npt) { memcpy(out + o_ps, phone_state, sizeof(int32_t) * npt); memcpy(out + o_pt, phone_token, sizeof(int32_t) * npt); }
+    int32_t* pdoff = out + o_pdoff;
+    int32_t* pdst = out + o_pdst;
+    size_t w = 0;
+    pdoff[0] = 0;
+    for (int p = 0; p <= nph; ++p) {
+        for (int32_t d : dsts[p]) pdst[w++] = d;
+        pdoff[p + 1] = (int32_t)w;
+    }
+    return WF_OK;
+}
+
 namespace {
 // open-addressing map (q, i) -> product state id, cleared per utterance
 struct PairMap {
@@ -684,8 +694,44 @@ struct ComposeScratch {
     PairMap id;
     std::vector<int64_t> order;
     std::vector<int32_t> arcs, aux;   // the composed graph of the last utterance: arcs [n][4] (final arcs: dst = -1), aux [n]
+    std::vector<int32_t> head_start, arcs2, aux2, newid, oldof;
+    std::vector<int32_t> pos;         // per product state (new numbering): its right-hand state (transcript position)
     int num_states = 0;
 };
+
+// Product states are DISCOVERED breadth first from (0, 0), but NUMBERED by (right-hand state r, topology state q): for a
+// linear transcript that is position-major order -- a numbering every position can compute for itself from a prefix sum,
+// which is what lets the device compiler (numerator_compile_kernel) emit the same graph without a sequential traversal.
+// (k2's own numbering in compose is parity unpinned: SURVEY 8(c).)  order[old id] = q * R + r; arcs [n][4] = {head, dst
+// or -1, label, weight} grouped by head in discovery order, head_start[h] = index of head h's first arc (n at the end).
+// Arcs keep their order within a state; X.pos receives r per new id.
+void renumber_position_major(ComposeScratch& X, int64_t R) {
+    const int n = (int)X.order.size();
+    X.oldof.resize(n);
+    for (int i = 0; i < n; ++i) X.oldof[i] = i;
+    const int64_t* key = X.order.data();
+    std::sort(X.oldof.begin(), X.oldof.end(), [&](int a, int b) {
+        const int64_t ra = key[a] % R, rb = key[b] % R;
+        return ra != rb ? ra < rb : key[a] < key[b];
+    });
+    X.newid.resize(n);
+    X.pos.resize(n);
+    for (int i = 0; i < n; ++i) { X.newid[X.oldof[i]] = i; X.pos[i] = (int32_t)(key[X.oldof[i]] % R); }
+    X.arcs2.resize(X.arcs.size());
+    X.aux2.resize(X.aux.size());
+    size_t w = 0;
+    for (int s2 = 0; s2 < n; ++s2) {
+        const int old = X.oldof[s2];
+        for (int a = X.head_start[old]; a < X.head_start[old + 1]; ++a, ++w) {
+            const int32_t* r = &X.arcs[4 * (size_t)a];
+            int32_t* o = &X.arcs2[4 * w];
+            o[0] = s2; o[1] = r[1] < 0 ? -1 : X.newid[r[1]]; o[2] = r[2]; o[3] = r[3];
+            X.aux2[w] = X.aux[a];
+        }
+    }
+    X.arcs.swap(X.arcs2);
+    X.aux.swap(X.aux2);
+}
 
 // compose(topo, linear transcript seq[0..L)) into X.arcs / X.aux (state ids in BFS order, super-final = X.num_states - 1)
 int compose_linear_one(const TopoView& tv, const int32_t* seq, int L, int b, ComposeScratch& X) {
@@ -710,7 +756,7 @@ int compose_linear_one(const TopoView& tv, const int32_t* seq, int L, int b, Com
         if (seq[i] < 1 || (ctc_cross && seq[i] >= tv.num_phones))
             return wf_fail(WF_ERANGE, "wf_compose_linear_batch: transcript %d position %d: phone %d out of range", b, i, seq[i]);
     id.reset(8 * (size_t)(L + 2));
-    order.clear(); arcs.clear(); aux.clear();
+    order.clear(); arcs.clear(); aux.clear(); X.head_start.clear();
     auto pkey = [&](int q, int i) { return (int64_t)q * (L + 1) + i; };
     bool ins;
     id.get(pkey(0, 0), 0, &ins);
@@ -723,6 +769,7 @@ int compose_linear_one(const TopoView& tv, const int32_t* seq, int L, int b, Com
         aux.push_back(phv);
     };
     for (size_t head = 0; head < order.size(); ++head) {
+        X.head_start.push_back((int32_t)aux.size());
         const int q = (int)(order[head] / (L + 1)), i = (int)(order[head] % (L + 1));
         const int lo = soff[q], hi = soff[q + 1];
         // runs of this state's arcs: final (key -1), phone 0, phone b[i]
@@ -781,7 +828,9 @@ int compose_linear_one(const TopoView& tv, const int32_t* seq, int L, int b, Com
                 aux.push_back(-1);
             }
     }
+    X.head_start.push_back((int32_t)aux.size());
     X.num_states = (int)order.size() + 1;
+    renumber_position_major(X, (int64_t)L + 1);
     return WF_OK;
 }
 
@@ -826,6 +875,33 @@ extern "C" int wf_compose_linear_batch(const int32_t* topo_arcs, const int32_t* 
         out_num_states[b] = X.num_states;
     }
     if (!fits) return wf_fail(WF_ENOSPC, "wf_compose_linear_batch: arc capacity %lld < %lld", (long long)cap, (long long)w);
+    return WF_OK;
+}
+
+// compose(topo, linear(phones) with epsilon self-loops), treat_epsilons_specially=False, for ONE transcript against a
+// topology given as plain arc arrays (the index of wf_topo_index_build is built for the call): the per-utterance form of
+// wf_compose_linear_batch, same graph.  Product states (q, i) numbered position-major (renumber_position_major); arcs
+// grouped by source state in the topology's arc order; the super-final state is last.
+extern "C" int wf_compose_linear(const int32_t* topo_arcs, const int32_t* topo_aux, int32_t nA,
+                                 int32_t nS, const int32_t* phones, int32_t L, int32_t* out_arcs,
+                                 int32_t* out_aux, int32_t* out_num_arcs, int32_t* out_num_states,
+                                 int32_t cap) {
+    if (!topo_arcs || !topo_aux || nA < 1 || nS < 2 || L < 0 || (!phones && L > 0) || !out_num_arcs || !out_num_states)
+        return wf_fail(WF_EINVAL, "wf_compose_linear: bad argument");
+    int64_t words = 0;
+    int rc = wf_topo_index_words(topo_arcs, topo_aux, nA, nS, &words);
+    if (rc) return rc;
+    std::vector<int32_t> index((size_t)words);
+    if ((rc = wf_topo_index_build(topo_arcs, topo_aux, nA, nS, index.data()))) return rc;
+    const TopoView tv{topo_arcs, topo_aux, nA, nS, index.data(), 0, nullptr, nullptr, 0};
+    ComposeScratch X;
+    if ((rc = compose_linear_one(tv, phones, L, 0, X))) return rc;
+    const int n = (int)X.aux.size();
+    *out_num_arcs = n;
+    *out_num_states = X.num_states;
+    if (!out_arcs) return WF_OK;
+    if (cap < n || !out_aux) return wf_fail(WF_ENOSPC, "wf_compose_linear: arc capacity %d < %d", cap, n);
+    compose_store(X, out_arcs, out_aux);
     return WF_OK;
 }
 
@@ -935,7 +1011,7 @@ extern "C" int wf_numerator_compile(const int32_t* topo_arcs, const int32_t* top
     const TopoView tv{topo_arcs, topo_aux, nA, nS, index, ctc_cross, phone_state, phone_token, num_phones};
     const int nw = std::max(1, std::min<int>(std::min<int>(nthreads, B), 16));
     // phase 1: every worker composes its (contiguous) share into its own buffers
-    struct Share { std::vector<int32_t> arcs, aux, narcs, nstates; int rc = 0; char err[512] = ""; };
+    struct Share { std::vector<int32_t> arcs, aux, narcs, nstates, pos; int rc = 0; char err[512] = ""; };
     std::vector<Share> shares(nw);
     auto range = [&](int w, int n, int* lo, int* hi) { *lo = (int)((int64_t)B * w / n); *hi = (int)((int64_t)B * (w + 1) / n); };
     WorkerPool::get().run(nw, [&](int w, int n) {
@@ -954,6 +1030,7 @@ extern "C" int wf_numerator_compile(const int32_t* topo_arcs, const int32_t* top
                 compose_store(X, S.arcs.data() + 4 * at, S.aux.data() + at);
                 S.narcs.push_back((int32_t)X.aux.size());
                 S.nstates.push_back(X.num_states);
+                S.pos.insert(S.pos.end(), X.pos.begin(), X.pos.end());   // num_states - 1 entries: the transcript positions
             }
         }
     });
@@ -990,9 +1067,12 @@ extern "C" int wf_numerator_compile(const int32_t* topo_arcs, const int32_t* top
                 memcpy(out_arcs + 4 * (size_t)out_arc_off[lo], S.arcs.data(), sizeof(int32_t) * S.arcs.size());
                 memcpy(out_aux + out_arc_off[lo], S.aux.data(), sizeof(int32_t) * S.aux.size());
             }
+            size_t pat = 0;
             for (int b = lo; b < hi && !rcs[sh]; ++b) {
                 size_t cur = start[b];
-                rcs[sh] = prepare_one(&gh, b, Bw, Bw + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * b, cur, start[b + 1], &maxlab[b]);
+                rcs[sh] = prepare_one(&gh, b, Bw, Bw + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * b, cur, start[b + 1], &maxlab[b],
+                                      S.pos.data() + pat);
+                pat += (size_t)out_num_states[b] - 1;
                 if (rcs[sh]) errs[sh] = wf_last_error();
             }
         }
@@ -1032,9 +1112,12 @@ extern "C" int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* top
     const int32_t* soff = index;
     const int32_t* perm = index + nS + 1;
     const int32_t* key = perm + nA;
-    PairMap id;
-    std::vector<int64_t> order;
-    std::vector<int32_t> arcs, aux, boff, cand, seen;
+    ComposeScratch X;
+    PairMap& id = X.id;
+    std::vector<int64_t>& order = X.order;
+    std::vector<int32_t>& arcs = X.arcs;
+    std::vector<int32_t>& aux = X.aux;
+    std::vector<int32_t> boff, cand, seen;
     int64_t w = 0;
     bool fits = out_arcs && out_aux;
     out_arc_off[0] = 0;
@@ -1054,7 +1137,7 @@ extern "C" int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* top
         }
         for (int s = 0; s < R; ++s) boff[s + 1] += boff[s];
         id.reset(8 * (size_t)(R + 2));
-        order.clear(); arcs.clear(); aux.clear();
+        order.clear(); arcs.clear(); aux.clear(); X.head_start.clear();
         auto pkey = [&](int q, int r) { return (int64_t)q * R + r; };
         bool ins;
         id.get(pkey(0, 0), 0, &ins);
@@ -1067,6 +1150,7 @@ extern "C" int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* top
             aux.push_back(ax);
         };
         for (size_t head = 0; head < order.size(); ++head) {
+            X.head_start.push_back((int32_t)aux.size());
             const int q = (int)(order[head] / R), r = (int)(order[head] % R);
             const int lo = soff[q], hi = soff[q + 1];
             const int32_t* ke = key + hi;
@@ -1098,6 +1182,8 @@ extern "C" int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* top
                         aux.push_back(-1);
                     }
         }
+        X.head_start.push_back((int32_t)aux.size());
+        renumber_position_major(X, (int64_t)R);      // (right-hand state, topology state) order, as for linear transcripts
         const int sf = (int)order.size();
         const int64_t n = (int64_t)aux.size();
         if (w + n > INT32_MAX) return wf_fail(WF_EUNSUPPORTED, "wf_compose_fsa_batch: more than 2^31 arcs");

@@ -115,3 +115,53 @@ enum {
     WF_U_SOFF = 22,  // number of states of the utterances before this one (big-graph sweep: alpha ping-pong buffers)
     WF_U_WORDS = 24,
 };
+
+// ---- sizes shared by the host compiler (wf_graph.cpp) and the device compiler (wf_compile.hip) ----------------------
+#if defined(__HIPCC__)
+#define WF_HD __host__ __device__
+#else
+#define WF_HD
+#endif
+WF_HD static inline size_t wf_pad4(size_t w) { return (w + 3) & ~(size_t)3; }
+// Upper bound of the words an FSA of S states and A arcs takes in the blob (O(1): no pass over the arcs).
+// K <= 2A + 1: compact columns K <= A; direct columns K = max_label + 1 <= 2 * (#distinct labels).
+WF_HD static inline size_t wf_fsa_words_bound(size_t S, size_t A) {
+    const size_t K = 2 * A + 1;
+    size_t w = 0;
+    w += wf_pad4(S + 1) + 4 * wf_pad4(A);                       // in_off, in_src, in_col, in_w, in_arc
+    w += wf_pad4(S + 1) + 4 * wf_pad4(A) + wf_pad4(4 * A);      // out_off, out_dst, out_col, out_w, out_arc, out_rec
+    w += wf_pad4(K + 1) + 4 * wf_pad4(A);                       // lab_off, lab_src, lab_dst, lab_w, lab_col
+    w += wf_pad4(K);                                            // labels
+    w += 3 * wf_pad4(A);                                        // fin_src, fin_w, fin_arc (NF <= A)
+    w += 2 * wf_pad4(S);                                        // heavy_in, heavy_out
+    w += 2 * wf_pad4(S) + wf_pad4(A);                           // finb_log, finb_max, arc_src
+    if (S - 1 <= 64 * WF_BAND_MAX_R)                            // banded form is only built for graphs one wavefront can hold
+        w += wf_pad4(S) + 2 * wf_pad4(S * (WF_BAND_MAX_BW + 1) * WF_BAND_MAX_M * 2);
+    w += wf_pad4(WF_HUB_MAX_NC) + wf_pad4((WF_HUB_MAX_G + 1) * (WF_HUB_MAX_G + 1) * WF_HUB_MAX_NC) + wf_pad4(A);   // hub form
+    return w;
+}
+
+// ---- topology tables of the device numerator compiler (wf_topo_device_build -> numerator_compile_kernel): int32 words,
+// offsets from the start of the table
+enum {
+    WF_T_MAGIC = 0, WF_T_NA, WF_T_NS, WF_T_CROSS, WF_T_NPH /* phones 1 .. NPH index pdst_off */, WF_T_MAXPH /* of the index */,
+    WF_T_OARCS /* [nA][4] */, WF_T_OAUX /* [nA] */, WF_T_OINDEX /* wf_topo_index_build's index */, WF_T_OPSTATE, WF_T_OPTOKEN /* ctc_cross */,
+    WF_T_OPDOFF /* [NPH + 2]: phone p's destination states are pdst[pdoff[p] .. pdoff[p+1]) */, WF_T_OPDST,
+    WF_T_MAXD /* most emitting arcs of one product state */, WF_T_WORDS, WF_T_NUMPH /* size of phone_state / phone_token */,
+    WF_T_HDR = 16
+};
+#define WF_TOPO_MAGIC 0x31544657  // "WFT1"
+// limits of the device compiler (graphs beyond them: status != 0, the caller compiles on the host)
+#define WF_NC_MAX_POS 256      // transcript positions L + 1
+#define WF_NC_MAX_CAND 8       // topology states alive at one position
+#define WF_NC_MAX_S (64 * WF_BAND_MAX_R + 1)
+#define WF_NC_MAX_A 1024       // emitting arcs
+#define WF_NC_MAX_NF 64
+#define WF_NC_MAX_K 1024
+// per-utterance capacities by transcript length L and the topology's WF_T_MAXD
+WF_HD static inline int wf_nc_state_cap(int L) { const int s = WF_NC_MAX_CAND * (L + 1) + 1; return s < WF_NC_MAX_S ? s : WF_NC_MAX_S; }
+WF_HD static inline int wf_nc_arc_cap(int L, int maxd) {
+    const long long a = (long long)(wf_nc_state_cap(L) - 1) * maxd;
+    return (int)(a < WF_NC_MAX_A ? a : WF_NC_MAX_A) + WF_NC_MAX_NF;
+}
+

@@ -29,6 +29,7 @@ class Fsa:
     requires_grad = False  # reference asserts this (models.py:272)
 
     def __init__(self, arcs, aux_labels, fsa_arc_offsets, fsa_num_states, utt2fsa=None):
+        self._pending = None      # device compiler (compile.py): the job whose results this object adopts on first use
         self.arcs = np.ascontiguousarray(arcs, dtype=np.int32).reshape(-1, 4)
         self.aux_labels = None if aux_labels is None else np.ascontiguousarray(aux_labels, dtype=np.int32)
         self.fsa_arc_offsets = np.ascontiguousarray(fsa_arc_offsets, dtype=np.int32)
@@ -38,6 +39,24 @@ class Fsa:
         self._blob_host = None
         self._blob_pin = None     # pinned torch tensor behind _blob_host (numerator compiler): asynchronous upload
         self._blob_dev = {}
+
+    # The FsaVec arrays of a graph vector built by the DEVICE compiler live on the device; the host copies are fetched the
+    # first time something asks for them (best_path's label extraction, tests) -- the loss path never does.
+    def _lazy(name):
+        def get(self):
+            if self._pending is not None and self.__dict__.get("_" + name) is None:
+                self._pending.fetch_arrays(self)
+            return self.__dict__.get("_" + name)
+
+        def put(self, v):
+            self.__dict__["_" + name] = v
+        return property(get, put)
+
+    arcs = _lazy("arcs")
+    aux_labels = _lazy("aux_labels")
+    fsa_arc_offsets = _lazy("fsa_arc_offsets")
+    fsa_num_states = _lazy("fsa_num_states")
+    del _lazy
 
     # ---- construction -----------------------------------------------------------------------
     @classmethod
@@ -92,6 +111,8 @@ class Fsa:
     # ---- views ------------------------------------------------------------------------------
     @property
     def num_fsas(self):
+        if self._pending is not None:
+            return self._pending.B
         return len(self.fsa_num_states)
 
     @property
@@ -144,6 +165,8 @@ class Fsa:
         return gh
 
     def blob_host(self):
+        if self._blob_host is None and self._pending is not None:
+            self._pending.finish(self)            # waits for the device compiler's header (or falls back to the host compiler)
         if self._blob_host is None:
             lib = _lib.lib()
             gh = self._graph_host_struct()
@@ -200,6 +223,10 @@ class Fsa:
     def blob_dev(self, device):
         device = torch.device(device)
         key = str(device)
+        if self._pending is not None:
+            self.blob_host()
+            if self._pending is not None:
+                self._pending.join_stream(device)   # the caller's stream waits for the compile kernels
         if key not in self._blob_dev:
             host = self.blob_host()
             if self._blob_pin is not None:
