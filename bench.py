@@ -465,12 +465,69 @@ def dropin_times(wl, steps):
                                     n.value, C.c_void_p(stream)))
 
     wall, host = _wall_and_host(fresh_dropin, steps)
-    out["fresh_graphs_dropin"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
-                                  "what": "new transcripts every step: compile_ctc_k2_graphs (compose + prepare, "
-                                          f"{wf.compile.host_threads()} host threads) + asynchronous upload + the drop-in loss + backward"}
+    out["fresh_graphs_dropin_host_compiler"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
+                                                "what": "new transcripts every step: compile_ctc_k2_graphs on the host (compose + prepare, "
+                                                        f"{wf.compile.host_threads()} host threads) + asynchronous upload + the drop-in loss + backward"}
     wall, host = _wall_and_host(fresh_fused, steps)
-    out["fresh_graphs"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
-                           "what": "new transcripts every step: compile + asynchronous upload + the fused wf_fb_logsum call"}
+    out["fresh_graphs_host_compiler"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
+                                         "what": "new transcripts every step, graphs compiled on the HOST (round 2's path): compile + "
+                                                 "asynchronous upload + the fused wf_fb_logsum call"}
+
+    # ---- the same with the DEVICE compiler (numerator_compile_kernel): the host uploads the transcripts and does no graph
+    # work.  One batch ahead, as a data loader prefetches: step i's loss is issued after step i + 1's compile kernels went to
+    # their own stream, so they run beside the loss kernels; the header the host plans with comes back asynchronously.
+    def compile_dev():
+        b = batches[it[0] % len(batches)]
+        it[0] += 1
+        return wf.compile_ctc_k2_graphs(topo, b, device=wl.dev)
+
+    pending = [compile_dev()]
+
+    def fused_on(fsa):
+        gh, gd = fsa.blob_host(), fsa.blob_dev(wl.dev)
+        lp = wl.lp
+        n = C.c_size_t(0)
+        _lib.check(lib.wf_fb_workspace_bytes(_np(gh), None, _np(wl.segs), wl.B, wl.B, wl.V, 0, 1, C.byref(n)))
+        ws = torch.empty(n.value, dtype=torch.uint8, device=wl.dev)
+        _lib.check(lib.wf_fb_logsum(_np(gh), _ptr(gd), None, _ptr(lp), lp.stride(0), lp.stride(1), wl.B, wl.T, wl.V,
+                                    _np(wl.segs), wl.B, 0.0, 0, _ptr(wl.gscale), _ptr(wl.tot), _ptr(wl.grad), _ptr(ws),
+                                    n.value, C.c_void_p(stream)))
+
+    def fresh_fused_dev():
+        nxt = compile_dev()            # step i + 1's graphs: enqueued on the compile stream
+        fused_on(pending.pop())        # step i's loss on the graphs compiled during step i - 1
+        pending.append(nxt)
+
+    def fresh_dropin_dev():
+        nxt = compile_dev()
+        dropin(pending.pop())
+        pending.append(nxt)
+
+    def fresh_fused_dev_serial():      # no prefetch: compile, wait for its header, loss
+        fused_on(compile_dev())
+
+    wall, host = _wall_and_host(fresh_fused_dev, steps)
+    out["fresh_graphs"] = {"ms_per_step": wall, "host_issue_ms_per_step": host, "compiled_on": pending[0].compiled_on,
+                           "what": "new transcripts every step, graphs compiled ON THE DEVICE one batch ahead "
+                                   "(compile_ctc_k2_graphs(device=...): ONE launch of numerator_compile_kernel on its own stream "
+                                   "beside the previous step's loss; it reads the transcripts from pinned host memory and writes "
+                                   "the words the host plans with back there, no copy is enqueued) + the fused wf_fb_logsum call"}
+    wall, host = _wall_and_host(fresh_fused_dev_serial, steps)
+    out["fresh_graphs_no_prefetch"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
+                                       "what": "the same without the one-batch prefetch: compile on the device, wait for its header, loss"}
+    wall, host = _wall_and_host(fresh_dropin_dev, steps)
+    out["fresh_graphs_dropin"] = {"ms_per_step": wall, "host_issue_ms_per_step": host,
+                                  "what": "new transcripts every step, compiled on the device one batch ahead + the drop-in loss + backward"}
+    # the compile kernels alone
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    cs = wf.compile._compile_stream(wl.dev)
+    torch.cuda.synchronize()
+    ev[0].record(cs)
+    for _ in range(10):
+        compile_dev()
+    ev[1].record(cs)
+    torch.cuda.synchronize()
+    out["compile_device_ms"] = ev[0].elapsed_time(ev[1]) / 10
     wf.set_output_beam_mode(wf.graph.DEFAULT_BEAM_MODE)
     return out
 

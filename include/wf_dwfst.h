@@ -185,6 +185,39 @@ int wf_numerator_compile_device(const int32_t* topo_tab, const void* topo_tab_de
                                 size_t blob_bytes, int32_t* arcs_dev, int32_t* aux_dev, int64_t arc_capacity,
                                 int32_t* meta_dev, void* work_dev, size_t work_bytes, void* stream);
 
+/* The same compiler as ONE launch per batch for a training loop (waterfall_amd/compile.py): the caller brings one device
+ * buffer of *dev_bytes (any allocator) and two PINNED, device-visible host buffers (hipHostMalloc / torch pin_memory); the
+ * kernel reads the transcripts from in_host and writes the words the host plans with into out_host itself, and the
+ * workgroup that finishes last closes the batch (arc offsets, WF_I_ARC_BASE, the blob header).  No copy is enqueued,
+ * nothing waits on the host.
+ * wf_numerator_compile_job_bytes: sizes for these transcript lengths, or (phones_off == NULL) the most any batch of B
+ *   transcripts can take; layout[5] = {meta words M, header words H, blob bytes (the blob starts dev_buf), byte offset of
+ *   the arc staging rows, arc capacity} (wf_numerator_compile_job returns the same five for the batch it ran).
+ * wf_numerator_compile_job: in_host = phones_off [B + 1] (phones_off[0] = 0) followed by the flat transcripts.  out_host
+ *   receives M + H words: meta (arc offsets [B + 1] | states [B] | status [B] | staging offsets [B] | the number of graphs
+ *   with direct label columns, padded to M) then the
+ *   blob's header and per-FSA info words (H) -- valid once wf_compile_job_wait(*job) returns.  The FsaVec arcs stay in
+ *   dev_buf as staging rows {src, dst, label, weight bits, aux label}: utterance b's rows start at row `staging offset
+ *   b`, arc offsets[b + 1] - arc offsets[b] of them (a loss never reads them; compile.py fetches them on demand).
+ *   main_stream != NULL: compile_stream first waits for what main_stream has queued so far (for a dev_buf whose
+ *   allocator orders reuse on main_stream); NULL: the caller vouches that compile_stream may write dev_buf at once.
+ *   in_host must stay untouched until the job has completed.  Labels < 1: WF_EINVAL.
+ *   reuse_of: 0, or the job that used this dev_buf before (a caller that recycles its buffers): compile_stream then also
+ *   waits for that job's kernel and for the event of wf_compile_job_release(reuse_of).
+ * wf_compile_job_release: the caller is done with the job's graphs; records, on the streams that read them, the event a
+ *   later job that reuses the buffer waits for.
+ * wf_compile_job_wait: blocks the host until the job has completed.  wf_compile_job_join: makes `stream` wait for the
+ *   job (no host wait).  Jobs are numbered per device; at most 64 are tracked at once (an older one is waited for when
+ *   its slot is taken).  No counterpart in the reference: its compiler runs on the host inside the training step. */
+int wf_numerator_compile_job_bytes(const int32_t* topo_tab, const int32_t* phones_off, int32_t B, size_t* dev_bytes,
+                                   size_t* out_words, int64_t* layout);
+int wf_numerator_compile_job(const int32_t* topo_tab, const void* topo_tab_dev, const int32_t* in_host, int32_t B,
+                             void* dev_buf, size_t dev_bytes, int32_t* out_host, size_t out_words, int32_t device,
+                             void* main_stream, void* compile_stream, int64_t reuse_of, int64_t* job, int64_t* layout);
+int wf_compile_job_wait(int32_t device, int64_t job);
+int wf_compile_job_join(int32_t device, int64_t job, void* stream);
+int wf_compile_job_release(int32_t device, int64_t job, void* const* streams, int32_t num_streams);
+
 /* The same for ARBITRARY epsilon-free right-hand graphs (one per utterance), e.g. the phone-level graph of a word
  * sequence under a lexicon with alternative pronunciations and optional silence (datapipe.py:244-254: L_inv o words,
  * inverted, epsilons removed, epsilon self-loops added, then k2.compose(topo, ., treat_epsilons_specially=False)).

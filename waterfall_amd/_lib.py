@@ -59,6 +59,11 @@ _SIGS = {
     "wf_topo_device_build": (C.c_int, [_p, _p, _i32, _i32, _p, _i64, _i32, _p, _p, _i32, _p, _i64, C.POINTER(_i64)]),
     "wf_numerator_compile_device_bytes": (C.c_int, [_p, _p, _i32, C.POINTER(_sz), C.POINTER(_i64), C.POINTER(_sz)]),
     "wf_numerator_compile_device": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _sz, _p, _p, _i64, _p, _p, _sz, _p]),
+    "wf_numerator_compile_job_bytes": (C.c_int, [_p, _p, _i32, C.POINTER(_sz), C.POINTER(_sz), _p]),
+    "wf_numerator_compile_job": (C.c_int, [_p, _p, _p, _i32, _p, _sz, _p, _sz, _i32, _p, _p, _i64, C.POINTER(_i64), _p]),
+    "wf_compile_job_release": (C.c_int, [_i32, _i64, _p, _i32]),
+    "wf_compile_job_wait": (C.c_int, [_i32, _i64]),
+    "wf_compile_job_join": (C.c_int, [_i32, _i64, _p]),
     "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),
     "wf_static_scratch_bytes": (C.c_int, [C.POINTER(_sz)]),
     "wf_debug_alloc_count": (C.c_int, [C.POINTER(C.c_int64)]),

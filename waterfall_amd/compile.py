@@ -10,7 +10,9 @@ verbatim: ``linear_fsa`` only records the label sequences, the two middle steps 
 record, and ``compose`` builds the product graphs.
 """
 import ctypes as C
+import collections
 import itertools
+import weakref
 import os
 
 import numpy as np
@@ -225,19 +227,24 @@ _COMPILE_STREAMS = {}
 
 
 def _compile_stream(device):
+    """The stream the compile kernels run on (one per device); device: a torch.device or its index."""
     import torch
-    s = _COMPILE_STREAMS.get(device.index)
+    di = device if isinstance(device, int) else device.index
+    s = _COMPILE_STREAMS.get(di)
     if s is None:
-        s = _COMPILE_STREAMS[device.index] = torch.cuda.Stream(device)
+        s = _COMPILE_STREAMS[di] = torch.cuda.Stream(torch.device("cuda", di))
     return s
 
 
-def _topo_device_table(topo, device):
-    """(host copy, device copy) of wf_topo_device_build's table for a topology; cached on the object per device."""
+def _topo_device_table(topo, di):
+    """(host copy, device copy, host address, device address) of wf_topo_device_build's table for a topology; cached on
+    the object per device index."""
     import torch
     tab = _topo_tables(topo)
-    cache = tab.setdefault("device_tables", {})
-    key = str(device)
+    cache = tab.get("device_tables")
+    if cache is None:
+        cache = tab["device_tables"] = {}
+    key = di
     if key not in cache:
         lib = _lib.lib()
         ps, pt = tab["phone_state"], tab["phone_token"]
@@ -248,111 +255,220 @@ def _topo_device_table(topo, device):
         _lib.check(lib.wf_topo_device_build(*args, None, 0, C.byref(n)))
         host = np.empty(n.value, dtype=np.int32)
         _lib.check(lib.wf_topo_device_build(*args, host.ctypes.data, host.size, C.byref(n)))
-        cache[key] = (host, torch.from_numpy(host).to(device))
+        dev = torch.from_numpy(host).to(torch.device("cuda", di))
+        cache[key] = (host, dev, host.ctypes.data, dev.data_ptr())
     return cache[key]
 
 
-class _DeviceCompileJob:
-    """One batch in flight through numerator_compile_kernel: the device buffers, the pinned copies of what the host needs
-    to plan the compute calls (blob header + per-FSA info words, arc offsets, states, status) and the event behind them."""
+class _PinnedSlot:
+    """Pinned staging for one job: the transcripts on their way up, the words the host plans with on their way back."""
 
-    def __init__(self, topo, lin, device, stream):
+    def __init__(self, n_in, n_out):
+        import torch
+        self.cap_in, self.cap_out = n_in, n_out
+        self.pin_in = torch.empty(n_in, dtype=torch.int32, pin_memory=True)
+        self.pin_out = torch.empty(n_out, dtype=torch.int32, pin_memory=True)
+        self.np_in, self.np_out = self.pin_in.numpy(), self.pin_out.numpy()
+        self.ptr_in, self.ptr_out = self.pin_in.data_ptr(), self.pin_out.data_ptr()
+        self.job = 0            # the job that used it last (wf_numerator_compile_job's number)
+        self.owner = None       # weak reference to that job's Python object, while it has not read its results out
+
+
+_SLOTS = {}       # device index -> [ring of _PinnedSlot, next]
+_NSLOTS = 8
+
+
+def _take_slot(dev_index, n_in, n_out):
+    ring = _SLOTS.get(dev_index)
+    if ring is None:
+        ring = _SLOTS[dev_index] = [[None] * _NSLOTS, 0]
+    k = ring[1]
+    ring[1] = (k + 1) % _NSLOTS
+    slot = ring[0][k]
+    if slot is not None:
+        owner = slot.owner() if slot.owner is not None else None
+        if owner is not None:
+            owner.detach()          # the job before reads its results out of the slot (waits for it if need be)
+        elif slot.job:
+            _lib.check(_lib.lib().wf_compile_job_wait(dev_index, slot.job))    # its upload must have left the slot
+        slot.owner, slot.job = None, 0
+    if slot is None or slot.cap_in < n_in or slot.cap_out < n_out:
+        def up(n):
+            return max(4096, 1 << int(n - 1).bit_length())
+        slot = ring[0][k] = _PinnedSlot(up(n_in), up(n_out))
+    return slot
+
+
+_BUF_POOL = {}     # (device index, bytes) -> deque of (device buffer, the job that used it last), oldest first
+_POOL_MIN, _POOL_MAX = 2, 8
+
+
+def _take_buf(di, nbytes, cs):
+    """A device buffer for one job: the one released longest ago (whose readers have long finished: the compile stream's wait
+    for them is a formality, and the new job starts beside the loss that is running), or a new one."""
+    import torch
+    q = _BUF_POOL.get((di, nbytes))
+    if q is not None and len(q) >= _POOL_MIN:
+        return q.popleft()
+    # allocated under the compile stream: the caching allocator hands out only blocks that stream may write at once
+    main = torch.cuda.current_stream(di)
+    torch.cuda.set_stream(cs)
+    try:
+        return torch.empty(nbytes // 4, dtype=torch.int32, device=cs.device), 0
+    finally:
+        torch.cuda.set_stream(main)
+
+
+_JOB_SIZES = {}    # (id of the topology's device table, B) -> (device bytes, host words) that hold ANY batch of B transcripts
+
+
+class _DeviceCompileJob:
+    """One batch in flight through numerator_compile_kernel (wf_numerator_compile_job): ONE device buffer (the blob, behind it
+    the arc staging rows and the work space), a pinned slot, and the job number whose event the host or a stream waits on."""
+
+    def __init__(self, topo, flat, lens, device, stream):
         import torch
         lib = _lib.lib()
-        self.topo, self.lin, self.device = topo, lin, device
-        self.B = B = len(lin)
-        host_tab, dev_tab = _topo_device_table(topo, device)
-        off = lin.off
-        nb, cap, nw = C.c_size_t(0), C.c_int64(0), C.c_size_t(0)
-        _lib.check(lib.wf_numerator_compile_device_bytes(host_tab.ctypes.data, off.ctypes.data, B, C.byref(nb), C.byref(cap), C.byref(nw)))
-        self.stream = stream if stream is not None else _compile_stream(device)
-        nhdr = (8 + 64 * B + 3) // 4 * 4
-        with torch.cuda.device(device), torch.cuda.stream(self.stream):
-            # (allocated under the compile stream: the caching allocator orders their reuse after this stream's work)
-            flat = lin.flat if lin.flat.size else np.zeros(1, dtype=np.int32)
-            host_in = torch.empty(flat.size + B + 1, dtype=torch.int32, pin_memory=True)
-            host_in[:flat.size] = torch.from_numpy(flat)
-            host_in[flat.size:] = torch.from_numpy(off)
-            dev_in = host_in.to(device, non_blocking=True)
-            self.blob = torch.empty(nb.value // 4, dtype=torch.int32, device=device)
-            self.arcs_dev = torch.empty((max(cap.value, 1), 4), dtype=torch.int32, device=device)
-            self.aux_dev = torch.empty(max(cap.value, 1), dtype=torch.int32, device=device)
-            self.meta_dev = torch.empty(3 * B + 1, dtype=torch.int32, device=device)
-            work = torch.empty(nw.value, dtype=torch.uint8, device=device)
-            _lib.check(lib.wf_numerator_compile_device(host_tab.ctypes.data, C.c_void_p(dev_tab.data_ptr()), C.c_void_p(dev_in.data_ptr()),
-                                                       C.c_void_p(dev_in[flat.size:].data_ptr()), off.ctypes.data, B,
-                                                       C.c_void_p(self.blob.data_ptr()), nb.value, C.c_void_p(self.arcs_dev.data_ptr()),
-                                                       C.c_void_p(self.aux_dev.data_ptr()), cap.value, C.c_void_p(self.meta_dev.data_ptr()),
-                                                       C.c_void_p(work.data_ptr()), nw.value, C.c_void_p(self.stream.cuda_stream)))
-            self.hdr_pin = torch.empty(nhdr, dtype=torch.int32, pin_memory=True)
-            self.meta_pin = torch.empty(3 * B + 1, dtype=torch.int32, pin_memory=True)
-            self.hdr_pin.copy_(self.blob[:nhdr], non_blocking=True)
-            self.meta_pin.copy_(self.meta_dev, non_blocking=True)
-            self.event = torch.cuda.Event()
-            self.event.record(self.stream)
-            self._keep = (host_in, dev_in, work, dev_tab)
-        self.joined = set()
+        self.dev_index = di = device.index if device.index is not None else torch.cuda.current_device()
+        self.topo, self.flat, self.lens = topo, flat, lens
+        self.B = B = lens.size
+        tabs = _topo_device_table(topo, di)
+        host_ptr, dev_ptr = tabs[2], tabs[3]
+        sizes = _JOB_SIZES.get((host_ptr, B))
+        if sizes is None:
+            nb, nw = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(lib.wf_numerator_compile_job_bytes(host_ptr, None, B, C.byref(nb), C.byref(nw), (C.c_int64 * 5)()))
+            sizes = _JOB_SIZES[(host_ptr, B)] = (nb.value, nw.value)
+        n = flat.size
+        n_in = B + 1 + n
+        self.slot = slot = _take_slot(di, n_in, sizes[1])
+        np_in = slot.np_in
+        np_in[0] = 0
+        np.cumsum(lens, out=np_in[1:B + 1])
+        np_in[B + 1:n_in] = flat
+        if int(np_in[B]) != n:
+            raise ValueError("linear_fsa: lengths do not add up to the number of labels")
+        cs = stream if stream is not None else _compile_stream(di)
+        self.compile_stream = cs.cuda_stream
+        self.job = 0
+        self.buf, reuse_of = _take_buf(di, sizes[0], cs)
+        self.joined = []
+        job = C.c_int64(0)
+        self.layout = lay = (C.c_int64 * 5)()
+        rc = lib.wf_numerator_compile_job(host_ptr, dev_ptr, slot.ptr_in, B, self.buf.data_ptr(), sizes[0], slot.ptr_out,
+                                          sizes[1], di, None, self.compile_stream, reuse_of, C.byref(job), lay)
+        if rc:
+            linear_fsa((flat, lens))     # (labels < 1: the same ValueError as on the host path)
+            _lib.check(rc)
+        self.job = slot.job = job.value
+        slot.owner = weakref.ref(self)
+        self.hdr = self.meta = None
+        self.device = cs.device
+
+    def __del__(self):
+        # the buffer goes back to the pool, with an event behind the streams that read the graphs
+        try:
+            if not self.job:
+                return
+            n = len(self.joined)
+            if n:
+                _lib.lib().wf_compile_job_release(self.dev_index, self.job, (C.c_void_p * n)(*self.joined), n)
+            q = _BUF_POOL.get((self.dev_index, self.buf.numel() * 4))
+            if q is None:
+                q = _BUF_POOL[(self.dev_index, self.buf.numel() * 4)] = collections.deque()
+            if len(q) < _POOL_MAX:
+                q.append((self.buf, self.job))
+            else:
+                import torch
+                for h in self.joined:      # dropped: the allocator must know who may still read it
+                    self.buf.record_stream(torch.cuda.ExternalStream(h, device=self.device))
+        except Exception:                  # (interpreter shutdown)
+            pass
+
+    def detach(self):
+        """Waits for the job and copies its results out of the pinned slot (which then serves another job)."""
+        if self.hdr is None:
+            _lib.check(_lib.lib().wf_compile_job_wait(self.dev_index, self.job))
+            M = self.layout[0]
+            out = self.slot.np_out
+            self.meta = out[:4 * self.B + 2].copy()
+            self.hdr = out[M:M + self.layout[1]].copy()
+            self.slot.owner = None
+            self.slot = None
 
     def finish(self, fsa):
         """Waits for the header; adopts the device blob, or -- when an utterance was beyond the kernel's limits -- compiles
         the batch on the host instead."""
-        self.event.synchronize()
-        hdr = self.hdr_pin.numpy()
-        if int(hdr[0]) == 0:        # the blob's magic word is 0: some status != 0
-            host = compose(self.topo, self.lin)
+        self.detach()
+        hdr = self.hdr
+        if hdr[0] == 0:        # the blob's magic word is 0: some status != 0
+            host = compose(self.topo, arc_sort(remove_epsilon_and_add_self_loops(linear_fsa((self.flat, self.lens)))))
             fsa._pending = None
             fsa.arcs, fsa.aux_labels = host.arcs, host.aux_labels
             fsa.fsa_arc_offsets, fsa.fsa_num_states = host.fsa_arc_offsets, host.fsa_num_states
             fsa._blob_host, fsa._blob_pin = host._blob_host, host._blob_pin
-            fsa.compiled_on = "host (device compiler status %s)" % sorted(set(int(x) for x in self.meta_pin.numpy()[2 * self.B + 1:]) - {0})
+            fsa.compiled_on = "host (device compiler status %s)" % sorted(set(int(x) for x in self.meta[2 * self.B + 1:3 * self.B + 1]) - {0})
             return
         fsa._blob_host = hdr
-        fsa._blob_dev[str(self.device)] = self.blob
+        fsa._blob_dev[str(self.device)] = self.buf        # (the blob starts the buffer; the arc staging rows sit behind it)
+        nd = int(self.meta[4 * self.B + 1])
+        fsa._all_compact, fsa._all_direct = nd == 0, nd == self.B
 
     def join_stream(self, device):
         import torch
-        cur = torch.cuda.current_stream(device)
-        if cur.cuda_stream not in self.joined and cur.cuda_stream != self.stream.cuda_stream:
-            cur.wait_event(self.event)
-            self.blob.record_stream(cur)
-            self.joined.add(cur.cuda_stream)
+        h = torch._C._cuda_getCurrentRawStream(self.dev_index)
+        if h not in self.joined:
+            self.joined.append(h)
+            if h != self.compile_stream:
+                _lib.check(_lib.lib().wf_compile_job_join(self.dev_index, self.job, h))
 
     def fetch_arrays(self, fsa):
         if fsa._blob_host is None:
             self.finish(fsa)
             if fsa._pending is None:
                 return
-        meta = self.meta_pin.numpy()
         B = self.B
-        off = meta[:B + 1].copy()
+        off = self.meta[:B + 1].copy()
         n = int(off[B])
         fsa.__dict__["_fsa_arc_offsets"] = off
-        fsa.__dict__["_fsa_num_states"] = meta[B + 1:2 * B + 1].copy()
-        fsa.__dict__["_arcs"] = self.arcs_dev[:n].cpu().numpy()
-        fsa.__dict__["_aux_labels"] = self.aux_dev[:n].cpu().numpy()
+        fsa.__dict__["_fsa_num_states"] = self.meta[B + 1:2 * B + 1].copy()
+        # (the job has completed -- detach waited for it -- so this copy needs no stream order of its own)
+        w0 = self.layout[3] // 4
+        rows = self.buf[w0:w0 + 5 * self.layout[4]].cpu().numpy().reshape(-1, 5)
+        so = self.meta[3 * B + 1:4 * B + 1]
+        rows = np.concatenate([rows[so[b]:so[b] + off[b + 1] - off[b]] for b in range(B)]) if n else rows[:0]
+        fsa.__dict__["_arcs"] = np.ascontiguousarray(rows[:, :4])
+        fsa.__dict__["_aux_labels"] = np.ascontiguousarray(rows[:, 4])
 
 
 def compile_ctc_k2_graphs_device(topo, targets, device, stream=None):
-    """compile_ctc_k2_graphs on the DEVICE: the transcripts are uploaded (one small asynchronous copy) and
-    numerator_compile_kernel builds the graphs and their prepared tables; the host does no graph work.  Returns at once; the
-    Fsa waits for the kernel's header (a few hundred bytes per utterance, copied back asynchronously) only when a compute
-    call plans with it, so a training loop that compiles step i + 1's graphs before it runs step i's loss hides the
-    compiler behind the loss kernels (the compile kernels run on a stream of their own).  Batches the kernel cannot take
-    (WF_NC_* limits in csrc/wf_internal.h) are compiled on the host, transparently."""
+    """compile_ctc_k2_graphs on the DEVICE: numerator_compile_kernel reads the transcripts from a pinned host buffer and
+    builds the graphs and their prepared tables; the host does no graph work and enqueues no copy.  Returns at once; the
+    Fsa waits for the kernel's header (a few hundred bytes per utterance, written to pinned host memory by the kernel)
+    only when a compute call plans with it, so a training loop that compiles step i + 1's graphs before it runs step i's
+    loss hides the compiler behind the loss kernels (the compile kernel runs on a stream of its own).  Batches the kernel
+    cannot take (WF_NC_* limits in csrc/wf_internal.h) are compiled on the host, transparently."""
     import torch
-    device = torch.device(device)
-    lin = arc_sort(remove_epsilon_and_add_self_loops(linear_fsa(targets)))
-    if len(lin) == 0:
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
+    if isinstance(targets, tuple) and len(targets) == 2:      # (flat labels, lengths), as a data loader holds them
+        flat = np.ascontiguousarray(targets[0], dtype=np.int32).reshape(-1)
+        lens = np.asarray(targets[1]).reshape(-1)
+    else:
+        lin = linear_fsa(targets)
+        flat, lens = lin.flat, np.diff(lin.off)
+    if lens.size == 0:
         raise ValueError("compose: empty batch")
     fsa = Fsa.__new__(Fsa)
-    fsa._pending = None
-    fsa.utt2fsa = None
-    fsa.device = device
-    fsa._blob_host = None
-    fsa._blob_pin = None
-    fsa._blob_dev = {}
-    fsa.compiled_on = "device"
-    for name in ("_arcs", "_aux_labels", "_fsa_arc_offsets", "_fsa_num_states"):
-        fsa.__dict__[name] = None
-    fsa._pending = _DeviceCompileJob(topo, lin, device, stream)
+    d = fsa.__dict__
+    d["_pending"] = None
+    d["utt2fsa"] = None
+    d["_blob_host"] = None
+    d["_blob_pin"] = None
+    d["_blob_dev"] = {}
+    d["compiled_on"] = "device"
+    d["_arcs"] = d["_aux_labels"] = d["_fsa_arc_offsets"] = d["_fsa_num_states"] = None
+    job = _DeviceCompileJob(topo, flat, lens, device, stream)
+    d["device"] = job.device
+    d["_pending"] = job
     return fsa

@@ -12,14 +12,19 @@
 //      reachable states, and the fewest frames an accepted path needs, fall out of it;
 //   3. state ids are a prefix sum over the positions; a state's arcs are enumerated by the lane that owns it, in the
 //      topology's order; arc offsets are prefix sums again;
-//   4. the incoming-arc CSR, the column-sorted arcs and the distinct labels are bitonic sorts in the LDS; the banded order
-//      is "by position, inside a position by depth, then by state" (prepare_one's pos_hint order).
+//   4. the distinct labels are a bitmap and its prefix popcounts; the incoming-arc CSR is gathered by the destination
+//      state (its sources sit at its own position and the one before); the column-sorted arcs are a stable counting sort
+//      (lanes with equal columns find each other with ballots); the banded order is "by position, inside a position by
+//      depth, then by state" (prepare_one's pos_hint order).
 // Limits (WF_NC_*): <= 256 positions, <= 8 live topology states per position, <= 257 states, <= 1024 arcs; anything else
 // sets the utterance's status and the caller compiles that batch on the host.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "../../include/wf_dwfst.h"
 #include "wf_internal.h"
@@ -37,6 +42,9 @@ namespace {
 constexpr int kNP = WF_NC_MAX_POS, kNC = WF_NC_MAX_CAND, kSMax = WF_NC_MAX_S, kAMax = WF_NC_MAX_A, kNFMax = WF_NC_MAX_NF,
               kKMax = WF_NC_MAX_K;
 constexpr int kInf = 0x3fffffff;
+constexpr int kMaxDevices = 64;
+constexpr int kBmWords = 2048;     // labels below 65536 take the bitmap route, anything above the sort
+constexpr int kNcDynWords = (kSMax + 1) + 2 * (kKMax + 1) + 2 * kBmWords + kNP * kNC / 4;
 constexpr unsigned kNinfBits = 0xff800000u;
 
 enum { NC_OK = 0, NC_LONG = 1, NC_PHONE = 2, NC_CAND = 3, NC_STATES = 4, NC_ARCS = 5, NC_FINALS = 6, NC_LABELS = 7, NC_SPACE = 8 };
@@ -113,6 +121,12 @@ struct NcArgs {
     int32_t* arcs;              // outputs of nc_finish_kernel: [A][4]
     int32_t* aux;               // [A]
     int32_t* meta;              // [B + 1] arc offsets | [B] states | [B] status
+    int prof;                   // measurement aid (WF_NC_PROFILE=1): workgroup 0 prints the cycles of its phases
+    // wf_numerator_compile_job: one launch.  The transcripts are read from (and the words the host plans with are written to)
+    // pinned host memory; the workgroup that finishes last does nc_finish_kernel's job for the batch, arc compaction aside.
+    int32_t* out_host;          // [meta_words] arc offsets [B + 1] | states [B] | status [B] | staging offsets [B] | graphs with direct columns, then the blob's header + info words
+    int meta_words;
+    unsigned* done;             // device counter (zero between jobs): workgroups that have finished
 };
 
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -142,6 +156,39 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
     return s - v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ int nc_dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+// min over each aligned group of 8 lanes, in every lane of the group (every lane of the wave active)
+__device__ __forceinline__ int nc_min8(int v) {
+    v = min(v, nc_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = min(v, nc_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = min(v, nc_dpp<0x141>(v));   // row_half_mirror: lane k of 8 <- lane 7 - k (the other quad)
+    return v;
+}
+// Longest same-position chains (self-loops aside) among the candidates in `allow`, by at most `max_rounds` sweeps in
+// (c, c2) ascending order: depth of candidate c in nibble c of the result; *changed = the last sweep still moved something.
+__device__ __forceinline__ unsigned nc_depths(unsigned long long m0, unsigned allow, int max_rounds, bool* changed) {
+    unsigned D = 0;
+    bool ch = true;
+    for (int rd = 0; rd < max_rounds && ch; ++rd) {
+        ch = false;
+        unsigned rows = allow;
+        while (rows) {
+            const int c = __ffs(rows) - 1;
+            rows &= rows - 1;
+            unsigned row = (unsigned)(m0 >> (c * 8)) & 0xffu & allow & ~(1u << c);
+            const unsigned dc = (D >> (4 * c)) & 15u;
+            while (row) {
+                const int c2 = __ffs(row) - 1;
+                row &= row - 1;
+                if (((D >> (4 * c2)) & 15u) < dc + 1) { D = (D & ~(15u << (4 * c2))) | ((dc + 1) << (4 * c2)); ch = true; }
+            }
+        }
+    }
+    *changed = ch;
+    return D;
+}
+
 // ascending bitonic sort of k[0 .. N), N a power of two >= 2, by one wavefront (blockDim.x == 64)
 __device__ void nc_sort(unsigned* k, const int N, const int lane) {
     for (int size = 2; size <= N; size <<= 1)
@@ -157,13 +204,6 @@ __device__ void nc_sort(unsigned* k, const int N, const int lane) {
     __syncthreads();
 }
 __device__ __forceinline__ int pow2_at_least(int n) { int N = 2; while (N < n) N <<= 1; return N; }
-// first index in sorted k[0 .. n) whose value is >= v
-__device__ __forceinline__ int nc_lower_bound(const unsigned* k, int n, unsigned v) {
-    int lo = 0, hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (k[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
 __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
     // ---- LDS
     __shared__ int32_t cand[kNP * kNC];                  // topology states that can be alive at position i, ascending
@@ -185,11 +225,24 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
     __shared__ __align__(4) unsigned char cellcnt[(kSMax - 1) * (WF_BAND_MAX_BW + 1)];
     __shared__ int32_t info[WF_INFO_WORDS];
     __shared__ int32_t s_status;
+    __shared__ int32_t s_seq[kNP];                       // the transcript (which may sit in host memory: read once)
+    extern __shared__ int32_t nc_dyn[];                  // kNcDynWords
+    int32_t* indeg = nc_dyn;                             // [kSMax + 1] in-degree, then the fill cursor of the incoming CSR
+    int32_t* colcnt = indeg + kSMax + 1;                 // [kKMax + 1] arcs per column
+    int32_t* colcur = colcnt + kKMax + 1;                // [kKMax + 1] fill cursor of the column-sorted arcs
+    unsigned* bm = (unsigned*)(colcur + kKMax + 1);      // [kBmWords] the labels in use, one bit each
+    int32_t* pre = (int32_t*)(bm + kBmWords);            // [kBmWords] labels in use below word w
+    unsigned char* necnt = (unsigned char*)(pre + kBmWords);   // [kNP * kNC] emitting arcs of candidate c at position i
 
     const int b = blockIdx.x, lane = threadIdx.x;
+    unsigned long long tp[12];
+    int ntp = 0;
+#define NC_MARK() do { if (p.prof) tp[ntp++] = __builtin_amdgcn_s_memtime(); } while (0)
+    NC_MARK();
     const NcTopo t = nc_topo(p.topo);
     const int off0 = p.phones_off[b], L = p.phones_off[b + 1] - off0;
-    const int32_t* seq = p.phones + off0;
+    for (int i = lane; i < min(L, kNP); i += 64) s_seq[i] = p.phones[off0 + i];
+    const int32_t* seq = s_seq;
     // this utterance's blob region and arc staging offset: sums of the capacities of the utterances before it
     size_t start = 0;
     long long acap0 = 0;
@@ -222,6 +275,7 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
             if (seq[i] < 1 || (t.cross && seq[i] >= t.numph)) fail(NC_PHONE);
     }
     // ---- 1. candidates per position
+    NC_MARK();
     if (ok()) {
         for (int i = lane; i <= L; i += 64) {
             int32_t* c = cand + i * kNC;
@@ -251,60 +305,55 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
         }
     }
     // ---- 2. arcs between candidates as bit matrices; an upper bound of the depth inside a position
+    NC_MARK();
     if (ok()) {
         for (int i = lane; i <= L; i += 64) {
             const int n = ncand[i], n2 = i < L ? ncand[i + 1] : 0;
             unsigned long long m0 = 0, tb = 0;
             for (int c = 0; c < n; ++c) {
-                nc_enum(t, cand[i * kNC + c], i, L, seq, [&](int q2, int adv, int, int, int) {
+                const int ne = nc_enum(t, cand[i * kNC + c], i, L, seq, [&](int q2, int adv, int, int, int) {
                     const int32_t* cc = cand + (i + adv) * kNC;
                     const int nn = adv ? n2 : n;
                     for (int c2 = 0; c2 < nn; ++c2)
                         if (cc[c2] == q2) { (adv ? tb : m0) |= 1ull << (c * 8 + c2); break; }
                 });
+                necnt[i * kNC + c] = (unsigned char)min(ne, 255);
             }
             m0bits[i] = m0;
             tbits[i] = tb;
             // longest chain of same-position arcs (self-loops aside), at most n - 1; n: a cycle (then this many rounds still bound every shortest path)
-            int depth[kNC];
-#pragma unroll
-            for (int c = 0; c < kNC; ++c) depth[c] = 0;
+            bool ch;
+            const unsigned D = nc_depths(m0, (1u << n) - 1, n, &ch);
             int mx = 0;
-            for (int r = 0; r < n; ++r) {
-                bool ch = false;
-#pragma unroll
-                for (int c = 0; c < kNC; ++c)
-#pragma unroll
-                    for (int c2 = 0; c2 < kNC; ++c2)
-                        if (c != c2 && c < n && c2 < n && ((m0 >> (c * 8 + c2)) & 1) && depth[c2] < depth[c] + 1) { depth[c2] = depth[c] + 1; ch = true; }
-                if (!ch) break;
-            }
-#pragma unroll
-            for (int c = 0; c < kNC; ++c) mx = max(mx, depth[c]);
+            for (int c = 0; c < n; ++c) mx = max(mx, (int)((D >> (4 * c)) & 15u));
             rounds[i] = (unsigned char)min(mx, n);
         }
     }
     // ---- 3. distance from the start, position by position: lane = (candidate c2) * 8 + (candidate c)
+    NC_MARK();
     if (ok()) {
-        const int c = lane & 7, c2 = lane >> 3;
+        const int c = lane & 7, c2 = lane >> 3, tl = c * 8 + c2;
         int dist = (c2 == 0) ? 0 : kInf;   // state 0 is the smallest topology state: candidate 0 of position 0
         auto relax = [&](unsigned long long bits, bool same_pos) {
-            const int dsrc = __shfl(dist, c * 8 + c2, 64);                  // the distance of candidate c
-            int v = (((bits >> (c * 8 + c2)) & 1) && !(same_pos && c == c2) && dsrc < kInf) ? dsrc + 1 : kInf;
-            v = min(v, __shfl_xor(v, 1, 64));
-            v = min(v, __shfl_xor(v, 2, 64));
-            v = min(v, __shfl_xor(v, 4, 64));
-            return v;                                                       // min over c, in every lane of candidate c2
+            const int dsrc = __builtin_amdgcn_ds_bpermute(tl << 2, dist);   // the distance of candidate c
+            const int v = (((bits >> tl) & 1) && !(same_pos && c == c2) && dsrc < kInf) ? dsrc + 1 : kInf;
+            return nc_min8(v);                                              // min over c, in every lane of candidate c2
         };
+        unsigned long long m0 = m0bits[0];
+        int nr = rounds[0], nc = ncand[0];
         for (int i = 0; i <= L; ++i) {
-            if (i > 0) dist = relax(tbits[i - 1], false);
-            const unsigned long long m0 = m0bits[i];
-            const int nr = rounds[i];
+            // (the next position's words are on their way while this one's rounds run)
+            const int i1 = min(i + 1, L);
+            const unsigned long long tb = tbits[i], m0n = m0bits[i1];
+            const int nrn = rounds[i1], ncn = ncand[i1];
             for (int r = 0; r < nr; ++r) dist = min(dist, relax(m0, true));
-            if (c == 0) distv[i * kNC + c2] = (c2 < ncand[i]) ? dist : kInf;
+            if (c == 0) distv[i * kNC + c2] = (c2 < nc) ? dist : kInf;
+            if (i < L) dist = relax(tb, false);
+            m0 = m0n; nr = nrn; nc = ncn;
         }
     }
     // ---- 4. reachable states, state ids (position-major), the banded order
+    NC_MARK();
     int S = 0;
     if (ok()) {
         for (int i = lane; i <= L; i += 64) {
@@ -333,28 +382,20 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
             const unsigned r = reach[i];
             const unsigned long long m0 = m0bits[i];
             const int n = ncand[i];
-            int depth[kNC];
-#pragma unroll
-            for (int c = 0; c < kNC; ++c) depth[c] = 0;
-            bool ch = true;
-            for (int rd = 0; rd <= n && ch; ++rd) {
-                ch = false;
-#pragma unroll
-                for (int c = 0; c < kNC; ++c)
-#pragma unroll
-                    for (int c2 = 0; c2 < kNC; ++c2)
-                        if (c != c2 && ((r >> c) & 1) && ((r >> c2) & 1) && ((m0 >> (c * 8 + c2)) & 1) && depth[c2] < depth[c] + 1) { depth[c2] = depth[c] + 1; ch = true; }
-            }
+            bool ch;
+            const unsigned D = nc_depths(m0, r, n + 1, &ch);
             if (ch) cyc = true;
             const int base = sbase[i];
-#pragma unroll
-            for (int c = 0; c < kNC; ++c) {
-                if (!((r >> c) & 1)) continue;
+            for (unsigned rr = r; rr; rr &= rr - 1) {
+                const int c = __ffs(rr) - 1;
                 const int id = base + __popc(r & ((1u << c) - 1));
+                const unsigned dc = (D >> (4 * c)) & 15u;
                 int rank = 0;
-#pragma unroll
-                for (int c2 = 0; c2 < kNC; ++c2)
-                    if (((r >> c2) & 1) && (depth[c2] < depth[c] || (depth[c2] == depth[c] && c2 < c))) ++rank;
+                for (unsigned r2 = r; r2; r2 &= r2 - 1) {
+                    const int c2 = __ffs(r2) - 1;
+                    const unsigned d2 = (D >> (4 * c2)) & 15u;
+                    if (d2 < dc || (d2 == dc && c2 < c)) ++rank;
+                }
                 st_q[id] = cand[i * kNC + c];
                 st_i[id] = (unsigned short)i;
                 st_c[id] = (unsigned short)c;
@@ -365,6 +406,7 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
         band_ok = !__any(cyc);
     }
     // ---- 5. arcs per state
+    NC_MARK();
     int A = 0, NF = 0, NA = 0;
     if (ok()) {
         int ce = 0, ca = 0, cf = 0;
@@ -373,7 +415,8 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
             int ne = 0, nf = 0;
             if (id < S - 1) {
                 const int q = st_q[id], i = st_i[id];
-                ne = nc_enum(t, q, i, L, seq, [&](int, int, int, int, int) {});
+                ne = necnt[i * kNC + st_c[id]];
+                if (ne == 255) fail(NC_ARCS);
                 nf = (i == L) ? t.f1s[q] - t.soff[q] : 0;
                 if (nf > 1) fail(NC_FINALS);   // (beta_T of a state with several final arcs is a log-sum: the host's job)
             }
@@ -386,8 +429,10 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
         if (lane == 0) { ebase[S - 1] = A; ebase[S] = A; abase[S - 1] = NA; fbase[S - 1] = NF; }
         if (A > kAMax || NA > acap) fail(NC_ARCS);
         if (NF > kNFMax) fail(NC_FINALS);
+        for (int s2 = lane; s2 <= S; s2 += 64) indeg[s2] = 0;
     }
     int max_label = -1, we = 1;
+    NC_MARK();
     if (ok()) {
         int32_t* st = p.stage + 5 * (size_t)acap0;
         int ml = -1, w0 = 1;
@@ -403,6 +448,7 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
                 const int dst = sbase[i2] + __popc((unsigned)reach[i2] & ((1u << c2) - 1));
                 const int j = eb + k, o = ab + k;
                 e_src[j] = (unsigned short)id; e_dst[j] = (unsigned short)dst; e_lab[j] = tok; e_w[j] = wbits; e_orig[j] = (unsigned short)o;
+                atomicAdd(&indeg[dst], 1);
                 int32_t* r = st + 5 * (size_t)o;
                 r[0] = id; r[1] = dst; r[2] = tok; r[3] = wbits; r[4] = phv;
                 ml = max(ml, tok);
@@ -424,35 +470,65 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
         we = wave_min_i32(w0);
     }
     // ---- 6. distinct labels and columns
+    NC_MARK();
     int K = 0, direct = 0;
     if (ok()) {
-        const int N = pow2_at_least(max(A, 2));
-        for (int j = lane; j < N; j += 64) keys[j] = j < A ? (unsigned)e_lab[j] : 0xffffffffu;
-        nc_sort(keys, N, lane);
+        const bool bitmap = max_label < 32 * kBmWords;
+        const int W = (max_label >> 5) + 1;   // (max_label = -1, no arcs: no words)
         int k0 = 0;
-        for (int j0 = 0; j0 < A; j0 += 64) {
-            const int j = j0 + lane;
-            const bool first = j < A && (j == 0 || keys[j] != keys[j - 1]);
-            const unsigned long long m = __ballot(first);
-            if (first) {
-                const int at = k0 + __popcll(m & ((1ull << lane) - 1));
-                if (at < kKMax) labs[at] = (int32_t)keys[j];
+        if (bitmap) {
+            for (int w = lane; w < W; w += 64) bm[w] = 0;
+            __syncthreads();
+            for (int j = lane; j < A; j += 64) atomicOr(&bm[e_lab[j] >> 5], 1u << (e_lab[j] & 31));
+            __syncthreads();
+            for (int w0 = 0; w0 < W; w0 += 64) {
+                const int w = w0 + lane;
+                int tot;
+                const int ex = wave_excl_scan(w < W ? __popc(bm[w]) : 0, lane, &tot);
+                if (w < W) pre[w] = k0 + ex;
+                k0 += tot;
             }
-            k0 += __popcll(m);
+        } else {
+            const int N = pow2_at_least(max(A, 2));
+            for (int j = lane; j < N; j += 64) keys[j] = j < A ? (unsigned)e_lab[j] : 0xffffffffu;
+            nc_sort(keys, N, lane);
+            for (int j0 = 0; j0 < A; j0 += 64) {
+                const int j = j0 + lane;
+                const bool first = j < A && (j == 0 || keys[j] != keys[j - 1]);
+                const unsigned long long m = __ballot(first);
+                if (first) {
+                    const int at = k0 + __popcll(m & ((1ull << lane) - 1));
+                    if (at < kKMax) labs[at] = (int32_t)keys[j];
+                }
+                k0 += __popcll(m);
+            }
         }
         direct = (max_label >= 0 && (long long)k0 * 2 >= (long long)max_label + 1) ? 1 : 0;
         K = direct ? max_label + 1 : k0;
         if (K > kKMax || k0 > kKMax) fail(NC_LABELS);
         __syncthreads();
-        if (s_status == NC_OK)
+        if (s_status == NC_OK) {
+            for (int k = lane; k <= K; k += 64) colcnt[k] = 0;
+            if (bitmap && !direct)
+                for (int w = lane; w < W; w += 64) {
+                    int at = pre[w];
+                    for (unsigned bits = bm[w]; bits; bits &= bits - 1) labs[at++] = w * 32 + __ffs(bits) - 1;
+                }
+            __syncthreads();
             for (int j = lane; j < A; j += 64) {
                 const int l = e_lab[j];
                 int col = l;
-                if (!direct) { int lo = 0, hi = k0; while (lo < hi) { const int mid = (lo + hi) >> 1; if (labs[mid] < l) lo = mid + 1; else hi = mid; } col = lo; }
+                if (!direct) {
+                    if (bitmap) col = pre[l >> 5] + __popc(bm[l >> 5] & ((1u << (l & 31)) - 1));
+                    else { int lo = 0, hi = k0; while (lo < hi) { const int mid = (lo + hi) >> 1; if (labs[mid] < l) lo = mid + 1; else hi = mid; } col = lo; }
+                }
                 e_col[j] = (unsigned short)col;
+                atomicAdd(&colcnt[col], 1);
             }
+        }
     }
     // ---- 7. the tables, in prepare_one's order
+    NC_MARK();
     if (ok()) {
         size_t cur = start;
         auto take = [&](size_t n) {
@@ -467,21 +543,15 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
         // incoming CSR: stable sort of the emitting arcs by destination
         {
             const int o_off = take(S + 1), o_src = take(A), o_col = take(A), o_w = take(A), o_arc = take(A);
-            const int N = pow2_at_least(max(A, 2));
-            for (int j = lane; j < N; j += 64) keys[j] = j < A ? ((unsigned)e_dst[j] << 16 | (unsigned)j) : 0xffffffffu;
-            nc_sort(keys, N, lane);
-            for (int q = lane; q < A; q += 64) {
-                const int j = keys[q] & 0xffff;
-                B_[o_src + q] = e_src[j]; B_[o_col + q] = e_col[j]; B_[o_w + q] = e_w[j]; B_[o_arc + q] = e_orig[j];
-            }
             const int o_h = take(S);
-            int nh = 0, maxin = 0, nover = 0, over = 0;
+            int nh = 0, maxin = 0, nover = 0, over = 0, carry = 0;
             for (int s0 = 0; s0 < S + 1; s0 += 64) {
                 const int s2 = s0 + lane;
-                int lo = 0, deg = 0;
-                if (s2 <= S) lo = nc_lower_bound(keys, A, (unsigned)s2 << 16);
-                if (s2 <= S) B_[o_off + s2] = lo;
-                if (s2 < S) deg = nc_lower_bound(keys, A, (unsigned)(s2 + 1) << 16) - lo;
+                const int deg = s2 < S ? indeg[s2] : 0;
+                int tot;
+                const int lo = carry + wave_excl_scan(deg, lane, &tot);
+                carry += tot;
+                if (s2 <= S) { B_[o_off + s2] = lo; indeg[s2] = lo; }
                 const bool hv = s2 < S && deg > WF_HEAVY_DEG;
                 const unsigned long long m = __ballot(hv);
                 if (hv) B_[o_h + nh + __popcll(m & ((1ull << lane) - 1))] = s2;
@@ -492,6 +562,19 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
                 over = max(over, wave_max_i32(ov ? s2 : 0));
             }
             for (int x = nh + lane; x < S; x += 64) B_[o_h + x] = 0;
+            __syncthreads();
+            // the arcs into state d leave the states of d's position and of the one before it; walking those in state
+            // order visits the arcs in arc order: the stable sort by destination, without the sort
+            for (int d = lane; d < S - 1; d += 64) {
+                const int i2 = st_i[d];
+                const int lo = sbase[max(i2 - 1, 0)], hi = sbase[i2 + 1];
+                int q = indeg[d];
+                for (int j = ebase[lo]; j < ebase[hi]; ++j)
+                    if (e_dst[j] == d) {
+                        B_[o_src + q] = e_src[j]; B_[o_col + q] = e_col[j]; B_[o_w + q] = e_w[j]; B_[o_arc + q] = e_orig[j];
+                        ++q;
+                    }
+            }
             if (lane == 0) {
                 info[WF_I_IN_OFF] = o_off; info[WF_I_IN_SRC] = o_src; info[WF_I_IN_COL] = o_col; info[WF_I_IN_W] = o_w; info[WF_I_IN_ARC] = o_arc;
                 info[WF_I_HEAVY_IN] = o_h; info[WF_I_NHEAVY_IN] = nh; info[WF_I_MAXIN] = maxin; info[WF_I_NOVER_IN] = nover; info[WF_I_OVER_IN] = over;
@@ -530,21 +613,38 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
         // column-sorted arcs
         {
             const int o_off = take(K + 1), o_src = take(A), o_dst = take(A), o_w = take(A), o_lab = take(K), o_lcol = take(A);
-            const int N = pow2_at_least(max(A, 2));
             __syncthreads();
-            for (int j = lane; j < N; j += 64) keys[j] = j < A ? ((unsigned)e_col[j] << 16 | (unsigned)j) : 0xffffffffu;
-            nc_sort(keys, N, lane);
-            for (int q = lane; q < A; q += 64) {
-                const int j = keys[q] & 0xffff;
-                B_[o_src + q] = e_src[j]; B_[o_dst + q] = e_dst[j]; B_[o_w + q] = e_w[j]; B_[o_lcol + q] = e_col[j];
-            }
-            int maxdeg = 0;
+            int maxdeg = 0, carry = 0;
             for (int k0 = 0; k0 < K + 1; k0 += 64) {
                 const int k = k0 + lane;
-                int lo = 0, deg = 0;
-                if (k <= K) { lo = nc_lower_bound(keys, A, (unsigned)k << 16); B_[o_off + k] = lo; }
-                if (k < K) deg = nc_lower_bound(keys, A, (unsigned)(k + 1) << 16) - lo;
+                const int deg = k < K ? colcnt[k] : 0;
+                int tot;
+                const int lo = carry + wave_excl_scan(deg, lane, &tot);
+                carry += tot;
+                if (k <= K) { B_[o_off + k] = lo; colcur[k] = lo; }
                 maxdeg = max(maxdeg, wave_max_i32(deg));
+            }
+            __syncthreads();
+            // stable counting sort by column, 64 arcs at a time: the lanes that hold one column find each other with a
+            // ballot per bit of the column, take consecutive places in lane order, and the last of them moves the cursor
+            const int nbits = 32 - __clz(max(K - 1, 1));
+            for (int j0 = 0; j0 < A; j0 += 64) {
+                const int j = j0 + lane;
+                const bool valid = j < A;
+                const int col = valid ? e_col[j] : 0;
+                unsigned long long peers = __ballot(valid);
+                for (int bit = 0; bit < nbits; ++bit) {
+                    const bool one = (col >> bit) & 1;
+                    const unsigned long long bb = __ballot(valid && one);
+                    peers &= one ? bb : ~bb;
+                }
+                if (valid) {
+                    const int rank = __popcll(peers & ((1ull << lane) - 1)), cnt = __popcll(peers);
+                    const int base = colcur[col], q = base + rank;
+                    B_[o_src + q] = e_src[j]; B_[o_dst + q] = e_dst[j]; B_[o_w + q] = e_w[j]; B_[o_lcol + q] = col;
+                    if (rank == cnt - 1) colcur[col] = base + cnt;
+                }
+                __syncthreads();
             }
             for (int k = lane; k < K; k += 64) B_[o_lab + k] = direct ? k : labs[k];
             if (lane == 0) {
@@ -643,14 +743,80 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
         __syncthreads();
         for (int w = lane; w < WF_INFO_WORDS; w += 64) I[w] = info[w];   // (WF_I_ARC_BASE: nc_finish_kernel)
     }
+    int32_t* IH = p.out_host ? p.out_host + p.meta_words + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * b : nullptr;
+    if (IH && s_status == NC_OK)
+        for (int w = lane; w < WF_INFO_WORDS; w += 64) IH[w] = info[w];
     __syncthreads();
+    NC_MARK();
+    if (p.prof && b == 0 && lane == 0) {
+        printf("numerator_compile_kernel wg 0 (L=%d S=%d A=%d): cycles setup %llu | candidates %llu | bit matrices %llu | distances %llu | ids+order %llu | arc counts %llu | arcs %llu | labels %llu | tables %llu\n",
+               L, S, A, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], tp[7] - tp[6], tp[8] - tp[7], tp[9] - tp[8]);
+    }
     const int status = s_status;
     if (status != NC_OK) {
-        for (int w = lane; w < WF_INFO_WORDS; w += 64) I[w] = 0;
+        for (int w = lane; w < WF_INFO_WORDS; w += 64) { I[w] = 0; if (IH) IH[w] = 0; }
         S = 0; NA = 0; max_label = -1;
     }
     if (lane == 0) {
         p.counts[b] = NA; p.counts[p.B + b] = S; p.counts[2 * p.B + b] = status; p.counts[3 * p.B + b] = max_label;
+    }
+    if (!p.done) return;
+    // ---- the last workgroup to get here finishes the batch (every workgroup arrives: no one waits for another)
+    __shared__ unsigned s_ticket;
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) s_ticket = atomicAdd(p.done, 1u);
+    __syncthreads();
+    if (s_ticket != (unsigned)p.B - 1) return;
+    __threadfence();
+    if (lane == 0) *p.done = 0;
+    const int Bn = p.B, M = p.meta_words;
+    int carry = 0, acarry = 0, bad = 0, gmaxS = 0, gmaxA = 0, gmaxlab = -1, ndirect = 0;
+    long long words = 0;
+    for (int u0 = 0; u0 < Bn; u0 += 64) {
+        const int u = u0 + lane;
+        const bool valid = u < Bn;
+        int n = 0, cap = 0;
+        if (valid) {
+            const int Lu = p.phones_off[u + 1] - p.phones_off[u];
+            const int Lcu = min(max(Lu, 0), kNP - 1);
+            n = p.counts[u];
+            cap = wf_nc_arc_cap(Lcu, t.maxd);
+            words += (long long)wf_fsa_words_bound((size_t)wf_nc_state_cap(Lcu), (size_t)cap);
+            bad |= p.counts[2 * Bn + u] != 0;
+            gmaxS = max(gmaxS, p.counts[Bn + u]);
+            gmaxlab = max(gmaxlab, p.counts[3 * Bn + u]);
+            gmaxA = max(gmaxA, p.blob[WF_HDR_WORDS + (size_t)WF_INFO_WORDS * u + WF_I_A]);
+            ndirect += p.blob[WF_HDR_WORDS + (size_t)WF_INFO_WORDS * u + WF_I_DIRECT] != 0;
+        }
+        int tot, atot;
+        const int ex = carry + wave_excl_scan(n, lane, &tot), aex = acarry + wave_excl_scan(cap, lane, &atot);
+        carry += tot; acarry += atot;
+        if (valid) {
+            p.blob[WF_HDR_WORDS + (size_t)WF_INFO_WORDS * u + WF_I_ARC_BASE] = ex;
+            p.out_host[M + WF_HDR_WORDS + (size_t)WF_INFO_WORDS * u + WF_I_ARC_BASE] = ex;
+            p.out_host[u] = ex;
+            p.out_host[Bn + 1 + u] = p.counts[Bn + u];
+            p.out_host[2 * Bn + 1 + u] = p.counts[2 * Bn + u];
+            p.out_host[3 * Bn + 1 + u] = aex;
+        }
+    }
+    ndirect = wave_sum_i32(ndirect);
+    if (lane == 0) { p.out_host[Bn] = carry; p.out_host[4 * Bn + 1] = ndirect; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) words += __shfl_xor(words, o, 64);
+    bad = __any(bad);
+    gmaxS = wave_max_i32(gmaxS); gmaxA = wave_max_i32(gmaxA); gmaxlab = wave_max_i32(gmaxlab);
+    if (lane < WF_HDR_WORDS) {
+        int32_t v = 0;
+        if (lane == WF_H_MAGIC) v = bad ? 0 : WF_BLOB_MAGIC;
+        if (lane == WF_H_NUM_FSAS) v = Bn;
+        if (lane == WF_H_WORDS) v = (int32_t)(wf_pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * Bn) + words);
+        if (lane == WF_H_MAX_LABEL) v = gmaxlab;
+        if (lane == WF_H_MAX_STATES) v = gmaxS;
+        if (lane == WF_H_MAX_ARCS) v = gmaxA;
+        p.blob[lane] = v;
+        p.out_host[M + lane] = v;
     }
 }
 
@@ -720,6 +886,77 @@ int nc_sizes(const int32_t* topo, const int32_t* phones_off, int B, size_t* blob
     return WF_OK;
 }
 
+static __device__ unsigned g_nc_done[64];   // per job slot: workgroups done (zero between jobs)
+unsigned* g_nc_done_ptr[kMaxDevices];
+
+// p: everything but prof, stage, counts, done; a: the batch's arc capacity; done_slot < 0: two launches (nc_finish_kernel
+// compacts the arcs), else one launch whose last workgroup closes the batch through g_nc_done[done_slot]
+int nc_launch(NcArgs p, long long a, void* work_dev, int done_slot, hipStream_t st) {
+    int32_t* work = (int32_t*)(((uintptr_t)work_dev + 255) & ~(uintptr_t)255);
+    p.stage = work; p.counts = work + 5 * (size_t)a;
+    static const int prof = getenv("WF_NC_PROFILE") ? atoi(getenv("WF_NC_PROFILE")) : 0;
+    p.prof = prof;
+    static std::once_flag lds_once[kMaxDevices];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return wf_fail(WF_EUNSUPPORTED, "device compiler: device %d", dev);
+    hipError_t lds_rc = hipSuccess;
+    std::call_once(lds_once[dev], [&] {
+        lds_rc = hipFuncSetAttribute((const void*)numerator_compile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(kNcDynWords * sizeof(int32_t)));
+        if (lds_rc == hipSuccess) lds_rc = hipGetSymbolAddress((void**)&g_nc_done_ptr[dev], HIP_SYMBOL(g_nc_done));
+    });
+    HIP_TRY(lds_rc);
+    if (!g_nc_done_ptr[dev]) return wf_fail(WF_EHIP, "device compiler: set-up failed earlier on device %d", dev);
+    p.done = done_slot >= 0 ? g_nc_done_ptr[dev] + done_slot : nullptr;
+    hipLaunchKernelGGL(numerator_compile_kernel, dim3(p.B), dim3(64), kNcDynWords * sizeof(int32_t), st, p);
+    if (done_slot < 0) hipLaunchKernelGGL(nc_finish_kernel, dim3(p.B), dim3(64), 0, st, p);
+    HIP_TRY(hipGetLastError());
+    return WF_OK;
+}
+
+// One event per job in flight: a ring per device; a slot is reused only once its previous job has completed.
+constexpr int kJobRing = 64;
+struct JobRing {
+    std::mutex mu;
+    hipEvent_t ev[kJobRing] = {};
+    hipEvent_t main_ev = nullptr;
+    int64_t seq_of[kJobRing] = {};
+    hipStream_t cs_of[kJobRing] = {};
+    hipEvent_t rel_ev[kJobRing] = {};      // wf_compile_job_release: the streams that read the job's graphs are past them
+    int64_t rel_seq[kJobRing] = {};
+    hipEvent_t tmp_ev = nullptr;
+    int64_t next = 1;
+};
+JobRing g_jobs[kMaxDevices];
+inline size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct JobLayout { size_t meta_words, blob_bytes, work_off, total, hdr_words; long long arc_cap; };
+int job_layout(const int32_t* topo_tab, const int32_t* phones_off, int B, JobLayout* L) {
+    size_t w = 0;
+    long long a = 0;
+    if (phones_off) {
+        int rc = nc_sizes(topo_tab, phones_off, B, &w, &a);
+        if (rc) return rc;
+        if (phones_off[0] != 0) return wf_fail(WF_EINVAL, "device compiler: phones_off[0] must be 0");
+    } else {   // the most any batch of B transcripts can take (the capacities are clamped at the kernel's limits)
+        if (!topo_tab || topo_tab[WF_T_MAGIC] != WF_TOPO_MAGIC) return wf_fail(WF_EINVAL, "device compiler: bad topology table");
+        if (B < 1) return wf_fail(WF_EINVAL, "device compiler: bad B");
+        const int Lc = kNP - 1;
+        a = (long long)B * wf_nc_arc_cap(Lc, topo_tab[WF_T_MAXD]);
+        w = wf_pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * B) +
+            (size_t)B * wf_fsa_words_bound((size_t)wf_nc_state_cap(Lc), (size_t)wf_nc_arc_cap(Lc, topo_tab[WF_T_MAXD]));
+        if (w >= (size_t)1 << 31) return wf_fail(WF_EUNSUPPORTED, "device compiler: prepared graph exceeds 2^31 words");
+    }
+    L->meta_words = (4 * (size_t)B + 2 + 63) / 64 * 64;
+    L->blob_bytes = w * 4;
+    L->work_off = up256(L->blob_bytes);
+    L->total = L->work_off + sizeof(int32_t) * (5 * (size_t)a + 4 * (size_t)B) + 256;
+    L->hdr_words = wf_pad4(WF_HDR_WORDS + (size_t)WF_INFO_WORDS * B);
+    L->arc_cap = a;
+    return WF_OK;
+}
+
 }  // namespace
 
 extern "C" int wf_numerator_compile_device_bytes(const int32_t* topo_tab, const int32_t* phones_off, int32_t B,
@@ -753,12 +990,125 @@ extern "C" int wf_numerator_compile_device(const int32_t* topo_tab, const void* 
     NcArgs p{};
     p.topo = (const int32_t*)topo_tab_dev; p.phones = phones_dev; p.phones_off = phones_off_dev; p.B = B;
     p.blob = (int32_t*)blob_dev; p.blob_words = (int64_t)(blob_bytes / 4);
-    int32_t* work = (int32_t*)(((uintptr_t)work_dev + 255) & ~(uintptr_t)255);
-    p.stage = work; p.counts = work + 5 * (size_t)a;
     p.arcs = arcs_dev; p.aux = aux_dev; p.meta = meta_dev;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(numerator_compile_kernel, dim3(B), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(nc_finish_kernel, dim3(B), dim3(64), 0, st, p);
-    HIP_TRY(hipGetLastError());
+    return nc_launch(p, a, work_dev, -1, (hipStream_t)stream);
+}
+
+extern "C" int wf_numerator_compile_job_bytes(const int32_t* topo_tab, const int32_t* phones_off, int32_t B, size_t* dev_bytes,
+                                              size_t* out_words, int64_t* layout) {
+    if (!dev_bytes || !out_words || !layout) return wf_fail(WF_EINVAL, "wf_numerator_compile_job_bytes: null pointer");
+    JobLayout L;
+    int rc = job_layout(topo_tab, phones_off, B, &L);
+    if (rc) return rc;
+    *dev_bytes = L.total;
+    *out_words = L.meta_words + L.hdr_words;
+    layout[0] = (int64_t)L.meta_words; layout[1] = (int64_t)L.hdr_words; layout[2] = (int64_t)L.blob_bytes;
+    layout[3] = (int64_t)L.work_off; layout[4] = (int64_t)L.arc_cap;
+    return WF_OK;
+}
+
+extern "C" int wf_numerator_compile_job(const int32_t* topo_tab, const void* topo_tab_dev, const int32_t* in_host, int32_t B,
+                                        void* dev_buf, size_t dev_bytes, int32_t* out_host, size_t out_words, int32_t device,
+                                        void* main_stream, void* compile_stream, int64_t reuse_of, int64_t* job,
+                                        int64_t* layout) {
+    if (!in_host || !topo_tab_dev || !dev_buf || !out_host || !job || !compile_stream)
+        return wf_fail(WF_EINVAL, "wf_numerator_compile_job: null pointer");
+    if (device < 0 || device >= kMaxDevices) return wf_fail(WF_EUNSUPPORTED, "wf_numerator_compile_job: device %d", device);
+    JobLayout L;
+    int rc = job_layout(topo_tab, in_host, B, &L);
+    if (rc) return rc;
+    if (dev_bytes < L.total || out_words < L.meta_words + L.hdr_words)
+        return wf_fail(WF_ENOSPC, "wf_numerator_compile_job: needs %zu B on the device and %zu words on the host", L.total,
+                       L.meta_words + L.hdr_words);
+    for (int32_t i = 0, n = in_host[B]; i < n; ++i)
+        if (in_host[B + 1 + i] < 1) return wf_fail(WF_EINVAL, "wf_numerator_compile_job: labels must be >= 1 (0 is epsilon)");
+    if (layout) {
+        layout[0] = (int64_t)L.meta_words; layout[1] = (int64_t)L.hdr_words; layout[2] = (int64_t)L.blob_bytes;
+        layout[3] = (int64_t)L.work_off; layout[4] = (int64_t)L.arc_cap;
+    }
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != device) HIP_TRY(hipSetDevice(device));
+    struct Restore { int cur, dev; ~Restore() { if (cur != dev) (void)hipSetDevice(cur); } } restore{cur, device};
+    JobRing& R = g_jobs[device];
+    std::lock_guard<std::mutex> lock(R.mu);
+    const int64_t seq = R.next;
+    const int slot = (int)(seq % kJobRing);
+    if (!R.ev[slot]) HIP_TRY(hipEventCreateWithFlags(&R.ev[slot], hipEventDisableTiming));
+    else if (R.seq_of[slot]) HIP_TRY(hipEventSynchronize(R.ev[slot]));   // (its counter g_nc_done[slot] is back at zero)
+    hipStream_t cs = (hipStream_t)compile_stream, ms = (hipStream_t)main_stream;
+    if (ms && ms != cs) {
+        // dev_buf comes from an allocator that orders reuse on the caller's stream: the compile stream starts behind what that
+        // stream has queued so far (never behind what it queues later: the loss of this step overlaps the compiler)
+        if (!R.main_ev) HIP_TRY(hipEventCreateWithFlags(&R.main_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(R.main_ev, ms));
+        HIP_TRY(hipStreamWaitEvent(cs, R.main_ev, 0));
+    }
+    if (reuse_of > 0) {
+        // dev_buf served job `reuse_of` before: behind that job's kernel (if it ran on another stream) and behind the streams
+        // that read its graphs (wf_compile_job_release).  A slot that has moved on: those events had completed by then.
+        const int rs = (int)(reuse_of % kJobRing);
+        if (R.seq_of[rs] == reuse_of && R.cs_of[rs] != cs) HIP_TRY(hipStreamWaitEvent(cs, R.ev[rs], 0));
+        if (R.rel_seq[rs] == reuse_of) HIP_TRY(hipStreamWaitEvent(cs, R.rel_ev[rs], 0));
+    }
+    // One launch: the kernel reads the transcripts from the pinned host buffer (once, into the LDS) and writes the words the
+    // host plans with straight into out_host; no copy is enqueued on either side.
+    NcArgs p{};
+    p.topo = (const int32_t*)topo_tab_dev; p.phones_off = in_host; p.phones = in_host + B + 1; p.B = B;
+    p.blob = (int32_t*)dev_buf; p.blob_words = (int64_t)(L.blob_bytes / 4);
+    p.out_host = out_host; p.meta_words = (int)L.meta_words;
+    rc = nc_launch(p, L.arc_cap, (char*)dev_buf + L.work_off, slot, cs);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(R.ev[slot], cs));
+    R.seq_of[slot] = seq;
+    R.cs_of[slot] = cs;
+    R.next = seq + 1;
+    *job = seq;
+    return WF_OK;
+}
+
+extern "C" int wf_compile_job_wait(int32_t device, int64_t job) {
+    if (device < 0 || device >= kMaxDevices || job < 1) return wf_fail(WF_EINVAL, "wf_compile_job_wait: bad job");
+    JobRing& R = g_jobs[device];
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(R.mu);
+        const int slot = (int)(job % kJobRing);
+        if (R.seq_of[slot] == job) ev = R.ev[slot];   // (a recycled slot: that job completed before the slot was taken again)
+    }
+    if (ev) HIP_TRY(hipEventSynchronize(ev));
+    return WF_OK;
+}
+
+extern "C" int wf_compile_job_join(int32_t device, int64_t job, void* stream) {
+    if (device < 0 || device >= kMaxDevices || job < 1) return wf_fail(WF_EINVAL, "wf_compile_job_join: bad job");
+    JobRing& R = g_jobs[device];
+    std::lock_guard<std::mutex> lock(R.mu);
+    const int slot = (int)(job % kJobRing);
+    if (R.seq_of[slot] == job) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, R.ev[slot], 0));
+    return WF_OK;
+}
+
+extern "C" int wf_compile_job_release(int32_t device, int64_t job, void* const* streams, int32_t num_streams) {
+    if (device < 0 || device >= kMaxDevices || job < 1 || num_streams < 0 || (num_streams && !streams))
+        return wf_fail(WF_EINVAL, "wf_compile_job_release: bad arguments");
+    if (num_streams == 0) return WF_OK;
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != device) HIP_TRY(hipSetDevice(device));
+    struct Restore { int cur, dev; ~Restore() { if (cur != dev) (void)hipSetDevice(cur); } } restore{cur, device};
+    JobRing& R = g_jobs[device];
+    std::lock_guard<std::mutex> lock(R.mu);
+    const int slot = (int)(job % kJobRing);
+    if (!R.rel_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&R.rel_ev[slot], hipEventDisableTiming));
+    else if (R.rel_seq[slot] && R.rel_seq[slot] != job) HIP_TRY(hipEventSynchronize(R.rel_ev[slot]));
+    hipStream_t first = (hipStream_t)streams[0];
+    for (int i = 1; i < num_streams; ++i) {      // the first stream gathers the others
+        if (!R.tmp_ev) HIP_TRY(hipEventCreateWithFlags(&R.tmp_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(R.tmp_ev, (hipStream_t)streams[i]));
+        HIP_TRY(hipStreamWaitEvent(first, R.tmp_ev, 0));
+    }
+    HIP_TRY(hipEventRecord(R.rel_ev[slot], first));
+    R.rel_seq[slot] = job;
     return WF_OK;
 }

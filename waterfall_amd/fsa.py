@@ -184,6 +184,8 @@ class Fsa:
         if v is None:
             from .csrc_layout import HDR_WORDS, INFO_WORDS, INFO
             b = self.blob_host()
+            if self.__dict__.get("_all_compact") is not None:      # (the device compiler counted while it built them)
+                return self._all_compact
             v = self._all_compact = bool((b[HDR_WORDS + INFO["DIRECT"]:HDR_WORDS + INFO_WORDS * self.num_fsas:INFO_WORDS] == 0).all())
         return v
 
@@ -194,6 +196,8 @@ class Fsa:
         if v is None:
             from .csrc_layout import HDR_WORDS, INFO_WORDS, INFO
             b = self.blob_host()
+            if self.__dict__.get("_all_direct") is not None:
+                return self._all_direct
             v = self._all_direct = bool((b[HDR_WORDS + INFO["DIRECT"]:HDR_WORDS + INFO_WORDS * self.num_fsas:INFO_WORDS] != 0).all())
         return v
 
@@ -256,6 +260,7 @@ def create_fsa_vec(fsas):
                 utt2fsa=np.zeros(len(fsas), dtype=np.int32))
         v._blob_host = f._blob_host
         v._blob_dev = f._blob_dev  # share uploads with the topology itself
+        v._shared_from = f         # (a device-compiled graph's buffer returns to the compiler's pool when f dies)
         return v
     arcs, aux, off, ns = [], [], [0], []
     for f in fsas:
