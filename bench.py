@@ -140,14 +140,15 @@ def _np(a):
 class Workload:
     """Synthetic batch (seed 777 + rank) resident on one GPU."""
 
-    def __init__(self, name, B, T, dev, seed, ragged=False, shard=None, beam=0.0):
+    def __init__(self, name, B, T, dev, seed, ragged=False, shard=None, beam=0.0, double=False):
         """shard = (rank, world): strong scaling -- the batch of B utterances is generated as a whole and this rank keeps
         the utterances waterfall_amd.dist.shard_batch deals it (round robin over the length-sorted order).
-        beam > 0: output_beam pruning (k2.intersect_dense's output_beam, graph.py:61-62,81): WF_PRUNED."""
+        beam > 0: output_beam pruning (k2.intersect_dense's output_beam, graph.py:61-62,81): WF_PRUNED.
+        double: use_double_scores=True (WF_DOUBLE_ACC | WF_TOT_F64: fp64 totals)."""
         w = WORKLOADS[name]
         self.name, self.T, self.dev = name, T, dev
         self.beam = float(beam)
-        self.flags = _lib.WF_PRUNED if beam > 0 else 0
+        self.flags = (_lib.WF_PRUNED if beam > 0 else 0) | ((_lib.WF_DOUBLE_ACC | _lib.WF_TOT_F64) if double else 0)
         P, L = w["P"], w["L"]
         rng = np.random.default_rng(seed)
         phones = ["<eps>", "<SIL>"] + ["p%d" % i for i in range(P)]
@@ -177,7 +178,7 @@ class Workload:
             self.fsa = wf.compile_ctc_k2_graphs(lazy, self.seqs)
         self.segs = np.stack([np.arange(B), np.zeros(B, dtype=np.int64), lens], 1).astype(np.int32)
         self.grad = torch.empty_like(self.lp)
-        self.tot = torch.empty(B, dtype=torch.float32, device=dev)
+        self.tot = torch.empty(B, dtype=torch.float64 if double else torch.float32, device=dev)
         self.gscale = torch.full((B,), -1.0, dtype=torch.float32, device=dev)
         self.gh = self.fsa.blob_host()
         self.gd = self.fsa.blob_dev(dev)
@@ -861,6 +862,21 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     others[key] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+            # use_double_scores=True (graph.py:83; every lattice_analysis.py call): fp64 totals from the same fast kernels
+            try:
+                w2 = Workload("cfg3_ctc_bpe5k_num", 32, args.frames, dev, seed=777, double=True)
+                n2 = max(5, args.steps // 5)
+                d2 = float(np.median(time_steps(w2, n2, 3, None, stream, fused[:3], min_region_s=0.03)))
+                exact_ms = ms_step if args.workload == "cfg3_ctc_bpe5k_num" else others.get("cfg3_ctc_bpe5k_num", {}).get("ms_per_step")
+                others["cfg3_double"] = {"frames_per_s": w2.frames / (d2 / n2), "ms_per_step": d2 / n2 * 1e3,
+                                         "float_ms_per_step": exact_ms, "fallback_utterances": w2.fallbacks(stream),
+                                         "desc": WORKLOADS["cfg3_ctc_bpe5k_num"]["desc"] + ", use_double_scores=True (WF_DOUBLE_ACC | "
+                                                 "WF_TOT_F64): fp64 totals from sweep_band_kernel, fp32 gradient",
+                                         "checked_by": "tests/test_gpu_parity.py::test_double_scores_cfg3_size_rtol_1e9"}
+                del w2
+            except Exception as e:   # noqa: BLE001
+                others["cfg3_double"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
             for S in (100_000, 1_000_000):
                 try:
                     others["cfg5_viterbi_S%.0e" % S] = viterbi_bench(dev, S)

@@ -58,7 +58,9 @@ extern "C" {
 #define WF_EUNSUPPORTED (-5)
 
 /* flags for wf_fb_logsum / wf_tot_scores / wf_viterbi */
-#define WF_DOUBLE_ACC 1u  /* accumulate alpha/beta in fp64 (k2 use_double_scores=True)            */
+#define WF_DOUBLE_ACC 1u  /* k2 use_double_scores=True: fp64 from the emissions to the total.  Graphs of the banded wave sweep
+                             (every numerator, the small denominators) keep the fast probability-domain kernels, whose
+                             recursion is fp64 anyway; the others take the log-semiring sweep with fp64 exp / log        */
 #define WF_TROPICAL 2u    /* wf_tot_scores only: max instead of log-sum-exp                       */
 #define WF_KEEP_AB 4u     /* wf_fb_logsum with grad == NULL: still run both sweeps and leave alpha/
                              beta in the workspace so that wf_fb_backward() can follow later       */
@@ -78,6 +80,9 @@ extern "C" {
                              with the flag, wf_fb_workspace_bytes says so beforehand).  Also taken by wf_fb_backward after a
                              wf_fb_logsum(WF_KEEP_AB, grad == NULL): the numerator's sweeps may then run on another stream
                              beside the denominator's.                                                                   */
+
+#define WF_TOT_F64 64u    /* wf_fb_logsum with WF_DOUBLE_ACC: `tot` is fp64 [B] (what get_tot_scores(use_double_scores=True)
+                             returns: graph.py:66, lattice_analysis.py:128); the gradient stays fp32 like log_probs      */
 
 typedef struct {
     int32_t num_fsas;                 /* G                                                     */

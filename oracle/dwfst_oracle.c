@@ -149,6 +149,31 @@ int oracle_graphloss_batch(int B, const int32_t *arc_off, const int32_t *nstates
     return 0;
 }
 
+/* The log-semiring totals of oracle_graphloss_batch(use_double = 1) WITHOUT the final rounding to fp32: what
+ * lattice.get_tot_scores(log_semiring=True, use_double_scores=True) returns (utils/lattice_analysis.py:128,148).    */
+int oracle_tot_scores_f64(int B, const int32_t *arc_off, const int32_t *nstates, const int32_t *src,
+                          const int32_t *dst, const int32_t *label, const float *score,
+                          const float *lp, int64_t strideB, int64_t strideT,
+                          const int32_t *seg, int nthreads, double *tot) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int i = 0; i < B; ++i) {
+        ograph g;
+        g.num_states = nstates[i];
+        g.num_arcs = arc_off[i + 1] - arc_off[i];
+        g.src = src + arc_off[i]; g.dst = dst + arc_off[i];
+        g.label = label + arc_off[i]; g.score = score + arc_off[i];
+        int b = seg[3 * i], st = seg[3 * i + 1], T = seg[3 * i + 2];
+        const float *lpb = lp + (size_t)b * strideB + (size_t)st * strideT;
+        double *w = (double *)malloc(sizeof(double) * (size_t)2 * (T + 1) * g.num_states);
+        tot[i] = fb_f64(&g, lpb, strideT, T, NULL, strideT, 1.f, w);
+        free(w);
+    }
+    return 0;
+}
+
 /* Tropical best path, fp32 arithmetic v = fl(alpha[src] + fl(w + lp)), ties -> lowest arc index
  * (see oracle/dwfst_oracle.py viterbi()).  path[T+1] receives arc ids local to the graph.
  * Returns the score; -inf when infeasible (path untouched).                                    */

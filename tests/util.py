@@ -67,6 +67,28 @@ def c_oracle_batch(lib, graphs, lp, segs, gscale=None, use_double=False, want_gr
     return tot, grad
 
 
+def c_oracle_tot_f64(lib, graphs, lp, segs, nthreads=1):
+    """oracle_tot_scores_f64: the fp64 log-semiring totals, not rounded to fp32."""
+    B = len(graphs)
+    off = np.zeros(B + 1, dtype=np.int32)
+    for i, g in enumerate(graphs):
+        off[i + 1] = off[i] + g["src"].size
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([g[k] for g in graphs]).astype(dt))
+    src, dst, lab = cat("src", np.int32), cat("dst", np.int32), cat("label", np.int32)
+    sc = cat("score", np.float32)
+    ns = np.array([g["num_states"] for g in graphs], dtype=np.int32)
+    lp = np.ascontiguousarray(lp, dtype=np.float32)
+    segs = np.ascontiguousarray(segs, dtype=np.int32)
+    tot = np.zeros(B, dtype=np.float64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.oracle_tot_scores_f64.restype = C.c_int
+    lib.oracle_tot_scores_f64.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+    rc = lib.oracle_tot_scores_f64(B, p(off), p(ns), p(src), p(dst), p(lab), p(sc), p(lp), lp.strides[0] // 4,
+                                   lp.strides[1] // 4, p(segs), nthreads, p(tot))
+    assert rc == 0
+    return tot
+
+
 def c_oracle_viterbi(lib, g, lp, T):
     lib.oracle_viterbi_f32.restype = C.c_float
     lib.oracle_viterbi_f32.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_void_p]

@@ -15,6 +15,7 @@ WF_KEEP_AB = 4
 WF_PRUNED = 8
 WF_PREZERO = 16
 WF_ACCUMULATE = 32
+WF_TOT_F64 = 64
 
 
 class WfError(RuntimeError):

@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_kernel(SweepArgs p) {
             Acc val = TROP ? m : lse_value(m, s);
             if (p.tot_double) ((double*)p.tot)[u] = (double)val;
             else ((float*)p.tot)[u] = (float)val;
-            if (MODE == M_FB && p.totd) p.totd[u] = (double)val;
+            if ((MODE == M_FB || MODE == M_TOT_LOG) && p.totd) p.totd[u] = (double)val;
             if (MASK && p.thr) p.thr[u] = p.best[u] - p.beam;
             if (MODE == M_VITERBI) p.fin_arc[u] = (m == neg_inf<Acc>()) ? -1 : barc;
         }
@@ -4775,7 +4775,7 @@ constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where not
 struct Hooks {
     int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
         zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache, no_pruned_fast,
-        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern, no_tab_kernarg, no_hub_split, hub_force_split;
+        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern, no_tab_kernarg, no_hub_split, hub_force_split, no_dbl_fast;
 };
 Hooks g_hooks;
 bool g_hooks_loaded = false;
@@ -4800,6 +4800,7 @@ void load_hooks() {
     h.no_hub = env_int("WF_NO_HUB_SWEEP", 0); h.no_hub_pattern = env_int("WF_NO_HUB_PATTERN", 0);
     h.no_tab_kernarg = env_int("WF_NO_TAB_KERNARG", 0); h.no_hub_split = env_int("WF_NO_HUB_SPLIT", 0);
     h.hub_force_split = env_int("WF_HUB_FORCE_SPLIT", 0);
+    h.no_dbl_fast = env_int("WF_NO_DOUBLE_FAST", 0);
     h.no_pruned_fast = env_int("WF_NO_PRUNED_FAST", 0);
     g_hooks = h;
     g_hooks_loaded = true;
@@ -4917,7 +4918,10 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
         // the small denominators); elsewhere: tropical + masked log-semiring sweeps (sweep_kernel / big_step_kernel)
         P->pruned_fast = pruned && acc_bytes == 8 && !dbl_exact && !P->big && band_config(*P).ok && post_small_fits(*P) &&
                          P->kmax <= kBandMaskKMax && !hk().no_pruned_fast;
-        P->lin = acc_bytes == 8 && !dbl_exact && !P->big &&
+        // WF_DOUBLE_ACC: the banded wave sweep is fp64 from the emission probabilities to the total (sweep_band_kernel); the
+        // other probability-domain kernels keep fp32 pieces, so their graphs take the fp64 log-semiring sweep
+        const bool dbl_fast = dbl_exact && !pruned && band_config(*P).ok && !hk().no_dbl_fast;
+        P->lin = acc_bytes == 8 && (!dbl_exact || dbl_fast) && !P->big &&
                  (pruned ? P->pruned_fast : (band_config(*P).ok || lin_config(*P).ok || hub_ok || linbig_config(*P)));
         P->hub = P->lin && !band_config(*P).ok && !lin_config(*P).ok && hub_ok;
         P->linbig = P->lin && !band_config(*P).ok && !lin_config(*P).ok && !P->hub;
@@ -5555,6 +5559,12 @@ extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2
     if ((flags & WF_ACCUMULATE) && (!P.lin || P.hub || !post_small_fits(P)))
         return wf_fail(WF_EUNSUPPORTED, "wf_fb_workspace_bytes: WF_ACCUMULATE is for graphs of the probability-domain path with at most 512 states / 1024 arcs (numerators)");
     *bytes = P.total + 256;
+    if ((flags & WF_DOUBLE_ACC) && !(flags & (WF_TROPICAL | WF_PRUNED | WF_KEEP_AB)) && !need_grad) {
+        // wf_tot_scores(WF_DOUBLE_ACC) runs the fp64 banded sweeps where they apply: room for their rows too
+        Plan Q;
+        if (plan_fb(graph_host, utt2fsa, seg, B, V, num_seqs, true, true, false, &Q, &fwd_via_fb) == WF_OK && Q.lin)
+            *bytes = std::max(*bytes, Q.total + 256);
+    }
     return WF_OK;
 }
 
@@ -5824,6 +5834,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
         return wf_fail(WF_EINVAL, "wf_fb_logsum: pass WF_PRUNED (also to wf_fb_workspace_bytes / wf_fb_backward) exactly when 0 < output_beam < inf");
     hipStream_t st = (hipStream_t)stream;
     const bool dbl = flags & WF_DOUBLE_ACC;
+    if ((flags & WF_TOT_F64) && !dbl) return wf_fail(WF_EINVAL, "wf_fb_logsum: WF_TOT_F64 goes with WF_DOUBLE_ACC");
     const bool need_ab = grad || (flags & WF_KEEP_AB);
     const size_t ab = 8;
     Plan P;
@@ -5866,6 +5877,14 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
     const bool postcheck = P.lin && grad && !(flags & WF_PREZERO) && !hk().no_post_check && !accum &&
                            (P.hub || ((overlap || !P.any_compact) && post_small_fits(P)));
     ForkGuard guard(st);   // every return below first makes `st` wait for the side stream
+    // the last step of a successful call.  WF_TOT_F64: every kernel left the total in the workspace in fp64 as well (the
+    // fp32 values they wrote into the front of `tot` are overwritten here)
+    auto finish = [&]() -> int {
+        int frc = guard.wait();
+        if (frc) return frc;
+        if (flags & WF_TOT_F64) HIP_TRY(hipMemcpyAsync(tot, ws + P.off_totd, sizeof(double) * B, hipMemcpyDeviceToDevice, st));
+        return WF_OK;
+    };
     g_tm.have_span = false;
     if (g_tm.on && P.lin && !P.hub && band_config(P).ok) {   // (reset in front of the timed intervals)
         void* sp = nullptr;
@@ -5997,7 +6016,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
             g_tm.have_fwd = g_tm.on;
             g_tm.have_check = g_tm.on;
             g_tm.check_from = 4;
-            return guard.wait();
+            return finish();
         }
         CheckArgs k{a.blob, a.utt, (const double*)a.alpha, (const double*)a.beta, a.aoff, a.boff, a.tot2, a.ctot2,
                     (int32_t*)(ws + P.off_flag), lgrp, llag,
@@ -6044,7 +6063,8 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
             BigArgs g{};
             g.blob = a.blob; g.utt = a.utt; g.lp = log_probs; g.strideB = strideB; g.strideT = strideT; g.E = a.E;
             g.tot = tot; g.tot_double = 0;
-            if (need_ab) { g.alpha = a.alpha; g.beta = a.beta; g.totd = a.totd; }
+            g.totd = a.totd;
+            if (need_ab) { g.alpha = a.alpha; g.beta = a.beta; }
             else g.buf = ws + P.off_big;
             if (!need_ab && P.shared) rc = dbl ? launch_big_shared<double, double, false>(P, ws, g, B, st) : launch_big_shared<double, float, false>(P, ws, g, B, st);
             else rc = dbl ? launch_big<double, double, false>(P, g, B, st) : launch_big<double, float, false>(P, g, B, st);
@@ -6067,7 +6087,7 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
         if ((rc = tm_record(4, st))) return rc;
         g_tm.have_post = g_tm.on;
     }
-    return guard.wait();
+    return finish();
 }
 }  // namespace
 
@@ -6401,6 +6421,17 @@ extern "C" int wf_tot_scores(const void* graph_host, const void* graph_dev, cons
     Plan P;
     int rc = check_segments("wf_tot_scores", seg, B, num_seqs, Tmax);
     if (rc) return rc;
+    if (dbl && !(flags & WF_TROPICAL)) {
+        // get_tot_scores(log_semiring=True, use_double_scores=True) (lattice_analysis.py:128,148): the fp64 banded sweeps
+        // where they apply (and the workspace is the one wf_fb_workspace_bytes(WF_DOUBLE_ACC, need_grad = 0) promised)
+        Plan Q;
+        bool via = false;
+        if (plan_fb(graph_host, utt2fsa, seg, B, V, num_seqs, true, true, false, &Q, &via) == WF_OK && Q.lin &&
+            Q.total + 256 <= workspace_bytes)
+            return fb_logsum_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, Tmax, V, seg, B, 0.0f,
+                                  WF_DOUBLE_ACC | WF_KEEP_AB | WF_TOT_F64, nullptr, (float*)tot, nullptr, workspace,
+                                  workspace_bytes, stream, false);
+    }
     rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, ab, 1, &P);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);

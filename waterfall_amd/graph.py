@@ -68,7 +68,8 @@ class _FbFunction(torch.autograd.Function):
         lib = _lib.lib()
         dev = lp.device
         N, T, V = lp.shape
-        flags = _lib.WF_DOUBLE_ACC if use_double_scores else 0
+        # use_double_scores: fp64 totals, as lattice.get_tot_scores(use_double_scores=True) returns them (graph.py:66)
+        flags = (_lib.WF_DOUBLE_ACC | _lib.WF_TOT_F64) if use_double_scores else 0
         need_grad = bool(ctx.needs_input_grad[0])
         if need_grad:
             flags |= _lib.WF_KEEP_AB
@@ -81,7 +82,7 @@ class _FbFunction(torch.autograd.Function):
         _lib.check(lib.wf_fb_workspace_bytes(_np_ptr(gh), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, N, V, flags,
                                               1 if need_grad else 0, C.byref(n)))
         ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
-        tot = torch.empty(B, dtype=torch.float32, device=dev)
+        tot = torch.empty(B, dtype=torch.float64 if use_double_scores else torch.float32, device=dev)
         grad = None
         if need_grad:
             # the gradient buffer is zero-filled beside the sweeps of this call (WF_PREZERO); backward only scatters
