@@ -4331,6 +4331,7 @@ struct SearchArgs {
     void* tot_log;
     int tot_double;
     int32_t* n_active;           // [B][Tmax+1] or null
+    int prof;                    // measurement aid (WF_SEARCH_PROFILE=1): workgroup 0 prints the cycles of its phases
 };
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -4404,6 +4405,10 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
     int64_t base_prev = 0;   // first record of the current frame's survivors
     bool dead = false;
     __syncthreads();
+    unsigned long long pc[5] = {0, 0, 0, 0, 0}, pt0 = 0;
+    long long parcs = 0, pcand = 0, ptight = 0;
+#define SR_MARK(i) do { if (p.prof) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pc[i] += now_ - pt0; pt0 = now_; } } while (0)
+    if (p.prof) pt0 = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < T; ++t) {
         const float* erow = lp0 + (int64_t)t * p.strideT;
         if (tid == 0) { s_ncand = 0; s_fmax = 0; s_nsurv = 0; s_min = 0xffffffffu; s_keepbin = 0x7fffffff; }
@@ -4441,6 +4446,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
             }
             __syncthreads();
             const int NA = s_narcs;
+            if (!log_pass) parcs += NA;
+            SR_MARK(0);
             for (int k0 = 0; k0 < NA; k0 += kSearchUnroll * kSearchThreads) {
                 int own[kSearchUnroll], q[kSearchUnroll];
                 bool ok[kSearchUnroll];
@@ -4508,6 +4515,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
             }
         }
         __syncthreads();   // every value of the pass is final
+        SR_MARK(1);
         }
         for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, o, 64));
         if (lane == 0 && lmax) atomicMax(&s_fmax, lmax);
@@ -4587,13 +4595,17 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
                 }
             }
         };
+        pcand += n;
+        SR_MARK(2);
         compact(true);
         for (int o = 32; o > 0; o >>= 1) lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, o, 64));
         if (lane == 0) atomicMin(&s_min, lmin);
         __syncthreads();
         const int cnt = s_nsurv;
         const bool tighten = cnt > cap, loosen = !tighten && cnt < want_min;
-        if (tighten || loosen) {   // (uniform) move the cut-off along a histogram of the scores (best first), compact again
+        SR_MARK(3);
+        if (tighten || loosen) {
+            ++ptight;   // (uniform) move the cut-off along a histogram of the scores (best first), compact again
             if (loosen) cutoff = ninf;
             const float lo = max(cutoff, ord2f(s_min));
             inv_width = fmax > lo ? (float)kSearchBins / (fmax - lo) : 0.f;
@@ -4638,7 +4650,11 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
         base_prev = base;
         base += nX;
         __syncthreads();
+        SR_MARK(4);
     }
+    if (p.prof && u == 0 && tid == 0)
+        printf("search_kernel wg 0: T=%d arcs %lld candidates %lld second-compaction frames %lld | cycles: scan %llu expand %llu reduce %llu compact %llu tighten+tail %llu\n",
+               T, parcs, pcand, ptight, pc[0], pc[1], pc[2], pc[3], pc[4]);
     // ---------------- final arcs over the survivors of frame T
     const int NF = I[WF_I_NF];
     const int32_t* fsrc = p.blob + I[WF_I_FIN_SRC];
@@ -6616,6 +6632,8 @@ extern "C" int wf_search(const void* graph_host, const void* graph_dev, const in
     a.best_score = best_score; a.best_arcs = best_arcs; a.Tmax = Tmax;
     a.tot_log = tot_log; a.tot_double = (flags & WF_DOUBLE_ACC) ? 1 : 0;
     a.n_active = n_active;
+    static const int search_prof = getenv("WF_SEARCH_PROFILE") ? atoi(getenv("WF_SEARCH_PROFILE")) : 0;
+    a.prof = search_prof;
     hipLaunchKernelGGL(search_kernel, dim3(B), dim3(kSearchThreads), 0, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;

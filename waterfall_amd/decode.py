@@ -13,9 +13,10 @@ materialised:
 * ``get_lattice`` -> the beam-pruned frame-synchronous search ``wf_search`` (graph.pruned_search): token passing with
   ``search_beam`` and ``min/max_active_states`` over decoding graphs of any size; it yields the best path, the tropical
   score and the log-semiring total of the pruned lattice in one pass.  ``search_beam=inf, max_active_states=0`` is the
-  exact search.  ``output_beam`` (k2: a backward pass that drops lattice arcs further than output_beam from the best
-  path) is applied as a second, tighter forward beam on the log-semiring total only when it is smaller than search_beam
-  -- k2's own beam arithmetic is parity unpinned (the reference holds no fixture), see INTEGRATION.md.
+  exact search.  ``output_beam`` of get_lattice (k2: a backward pass that drops lattice arcs further than output_beam
+  from the best path) is accepted and NOT applied: the log-semiring total is over every path through the states that
+  survived ``search_beam``, a superset of k2's output lattice (the best path and the tropical score do not depend on it).
+  k2's own beam arithmetic is parity unpinned (the reference holds no fixture), see INTEGRATION.md.
 * ``intersect_dense(graphs, dense, output_beam)`` -> the exact sweeps (wf_tot_scores / wf_viterbi) over the whole
   product, as in training (graph.py:61-62).
 """

@@ -26,7 +26,7 @@ def synth_decoding_graph(seed, S, V, hubs=4, hub_fan_in=300):
             "score": sc[order], "aux": lab[order].copy(), "num_states": S}
 
 
-def cfg5_workload(dev, S, B=8, T=500, V=5001, seed=777, peaked=False):
+def cfg5_workload(dev, S, B=8, T=500, V=5001, seed=777, peaked=False, peak=10.0):
     """BASELINE.md cfg5 as bench.py times it and tests/test_gpu_parity.py checks it: one synthetic TLG-like graph
     (A = 3 S) shared by B utterances, log_softmax(randn * 3) drawn on the device.  Returns (graph dict, Fsa vector,
     log_probs [B,T,V] on dev, DenseFsaVec).
@@ -34,7 +34,8 @@ def cfg5_workload(dev, S, B=8, T=500, V=5001, seed=777, peaked=False):
     peaked: the posterior of a trained model instead of noise -- per utterance a complete path of the graph is planted
     (the exact best path under the noise posterior) and log_probs = log_softmax(randn + 10 * onehot(its label)), about
     0.7 of every frame's mass on the planted label: the workload of the beam-pruned search (a beam has nothing to hold
-    on to in pure noise)."""
+    on to in pure noise).  peak: the planted label's logit boost (10: a confident model, a search beam of 20 keeps a few
+    dozen states; 4-6: the 10^3 - 10^4 active states of real decoding)."""
     import torch
     from .fsa import DenseFsaVec, Fsa, create_fsa_vec
     g = synth_decoding_graph(seed, S, V)
@@ -49,7 +50,7 @@ def cfg5_workload(dev, S, B=8, T=500, V=5001, seed=777, peaked=False):
         arcs_best = best_path(fsa, dense)["arcs"][:, :T].cpu().numpy()
         lab = torch.from_numpy(g["label"][arcs_best].astype(np.int64)).to(dev)
         z = torch.randn(B, T, V, generator=gen, device=dev)
-        z.scatter_add_(2, lab.unsqueeze(-1), torch.full((B, T, 1), 10.0, device=dev))
+        z.scatter_add_(2, lab.unsqueeze(-1), torch.full((B, T, 1), float(peak), device=dev))
         lp = torch.log_softmax(z, -1)
         dense = DenseFsaVec(lp, torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32))
     return g, fsa, lp, dense
