@@ -591,6 +591,68 @@ def search_bench(dev, S, B=8, T=500, V=5001, beam=20.0, max_active=10000, reps=3
                     f"max_active_states={max_active}, peaked synthetic posterior; wall time of wf.pruned_search incl. host"}
 
 
+def ctc_matrices(targets, V, dev):
+    """The (trans [B,S,S], transform [B,S,V], trans_lengths [B]) a CTC target sequence turns into for the reference's
+    manual_ctc losses (blank = 0; S = 2 L + 1: blank, label, blank, ..., blank), built on the device; finfo.min marks
+    "not allowed" as deprecated/datapipe_manual_ctc.py:245-281 pads."""
+    B, L = targets.shape
+    S = 2 * L + 1
+    fmin = torch.finfo(torch.float32).min
+    trans = torch.full((B, S, S), fmin, dtype=torch.float32, device=dev)
+    i = torch.arange(L, device=dev)
+    trans[:, 2 * i, 2 * i] = 0.0
+    trans[:, 2 * i[1:], 2 * i[1:] - 1] = 0.0
+    trans[:, 2 * i + 1, 2 * i + 1] = 0.0
+    trans[:, 2 * i + 1, 2 * i] = 0.0
+    b, k = torch.nonzero(targets[:, 1:] != targets[:, :-1], as_tuple=True)     # label k + 1 differs from label k: skip the blank
+    trans[b, 2 * (k + 1) + 1, 2 * (k + 1) - 1] = 0.0
+    trans[:, S - 1, S - 1] = 0.0
+    trans[:, S - 1, S - 2] = 0.0
+    transform = torch.full((B, S, V), fmin, dtype=torch.float32, device=dev)
+    transform[:, 0::2, 0] = 0.0
+    transform[torch.arange(B, device=dev)[:, None], (2 * i + 1)[None, :], targets] = 0.0
+    return trans, transform, torch.full((B,), S, dtype=torch.int64, device=dev)
+
+
+def manual_ctc_bench(dev, B=32, T=500, V=59, L=80, reps=20):
+    """The reference's manual_ctc loss (waterfall/manual_ctc/ctc.py:94-105: ctc_loss(log_probs, input_lengths, trans,
+    trans_lengths, transform)) through its drop-in at cfg2's sizes: matrices -> graph (built on the device, one copy to
+    the host) -> forward-backward kernels -> backward().  The reference's own implementation materialises a
+    [B, T, S, V] broadcast per call."""
+    from waterfall_amd import manual_ctc
+    gen = torch.Generator(device=dev).manual_seed(777)
+    x = torch.log_softmax(torch.randn(B, T, V, generator=gen, device=dev) * 3.0, -1).requires_grad_(True)
+    targets = torch.randint(1, V, (B, L), generator=gen, device=dev)
+    trans, transform, lens = ctc_matrices(targets, V, dev)
+    il = torch.full((B,), T, dtype=torch.int64)
+
+    def step():
+        x.grad = None
+        loss = manual_ctc.ctc_loss(x, il, trans, lens, transform, reduction="sum")
+        loss.backward()
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        l = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        manual_ctc.matrices_to_fsa(trans, lens, transform)
+    ms_graph = (time.perf_counter() - t0) / reps * 1e3
+    # the same loss from torch's own CTC on the same targets (blank 0): the check of this line
+    ref = torch.nn.functional.ctc_loss(x.detach().transpose(0, 1), targets, il, torch.full((B,), L, dtype=torch.int64),
+                                       blank=0, reduction="sum")
+    return {"ms_per_step": ms, "frames_per_s": B * T / (ms * 1e-3), "graph_build_ms": ms_graph,
+            "loss": float(l.item()), "torch_ctc_loss_same_inputs": float(ref.item()),
+            "desc": f"manual_ctc.ctc_loss + backward, B={B}, T={T}, V={V}, L={L} (S={2 * L + 1}); graph_build_ms = matrices_to_fsa "
+                    "alone (masked nonzero on the device + one copy + table preparation on the host)",
+            "checked_by": "tests/test_gpu_parity.py::test_manual_ctc_dropin_against_reference_goldens"}
+
+
 def num_den_bench(dev, B=32, T=500, P=5000, L=64, reps=10):
     """The numerator - denominator loss of the reference's k2 branch (rnnp.py:64-104) at cfg4 mmictc sizes under
     autograd: graphloss(num) - graphloss(den) (what the reference's lines do, unchanged) beside graphloss_num_den
@@ -876,6 +938,11 @@ def main():
                 del w2
             except Exception as e:   # noqa: BLE001
                 others["cfg3_double"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            try:
+                others["manual_ctc_cfg2"] = manual_ctc_bench(dev)
+            except Exception as e:   # noqa: BLE001
+                others["manual_ctc_cfg2"] = {"error": repr(e)}
             torch.cuda.empty_cache()
             for S in (100_000, 1_000_000):
                 try:

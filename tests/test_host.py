@@ -321,3 +321,32 @@ def test_numerator_compiler_works_in_a_forked_child():
     out = os.read(r, 1)
     os.close(r)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0 and out == b"\x00"
+
+
+def test_manual_ctc_matrices_to_fsa_vectorised_equals_the_loop():
+    # the batched masked-nonzero build of the graph (one-hot transform rows) against the per-utterance loop kept for rows
+    # with several tokens: the same FsaVec, arc for arc
+    import torch
+    from oracle import graphs as og
+    from waterfall_amd import manual_ctc
+    rng = np.random.default_rng(5)
+    V = 11
+    mats = [og.ctc_trans_transform(rng.integers(1, V, size=n).tolist(), V) for n in (5, 1, 8, 3)]
+    S = max(m[0].shape[0] for m in mats)
+    B = len(mats)
+    trans = np.full((B, S, S), og.FMIN, dtype=np.float32)
+    transform = np.full((B, S, V), og.FMIN, dtype=np.float32)
+    lens = np.zeros(B, dtype=np.int64)
+    for b, (t, f) in enumerate(mats):
+        s_ = t.shape[0]
+        trans[b, :s_, :s_] = t + rng.normal(size=t.shape).astype(np.float32) * (t > og.FMIN / 2)   # weighted transitions
+        transform[b, :s_] = f
+        lens[b] = s_
+    trans[0, 1, 7] = 0.5          # a transition out of a padded... no: inside utterance 0 (S_0 = 11): a backward jump
+    tt, tf, tl = torch.from_numpy(trans), torch.from_numpy(transform), torch.from_numpy(lens)
+    a = manual_ctc.matrices_to_fsa(tt, tl, tf)
+    b_ = manual_ctc._matrices_to_fsa_multi(tt, lens, tf, tf > manual_ctc._THR)
+    assert np.array_equal(a.arcs, b_.arcs)
+    assert np.array_equal(a.fsa_arc_offsets, b_.fsa_arc_offsets) and np.array_equal(a.fsa_num_states, b_.fsa_num_states)
+    with pytest.raises(ValueError):
+        manual_ctc.matrices_to_fsa(tt, torch.tensor([0, 3, 17, 7]), tf)

@@ -25,38 +25,72 @@ _THR = float(np.finfo(np.float32).min) / 2
 
 
 def matrices_to_fsa(trans: torch.Tensor, trans_lengths: torch.Tensor, transform: torch.Tensor) -> Fsa:
-    """(trans, trans_lengths, transform) -> FsaVec of B graphs (see the module docstring)."""
+    """(trans, trans_lengths, transform) -> FsaVec of B graphs (see the module docstring).
+
+    Built where the matrices live: the allowed (source j, destination i) pairs of the whole batch are ONE masked
+    ``nonzero`` over [B, S, S + 1] (column S = the final arc of source j), which already comes out in k2's arc order
+    (utterance, source state, destination; the final arc last); the host receives the finished arc list (one copy) and
+    only prepares the tables.  Rows of ``transform`` that allow several tokens (not produced by the reference's data
+    pipe, whose rows are one-hot: deprecated/datapipe_manual_ctc.py:245-281) take the per-utterance loop below."""
     B, S, _ = trans.shape
+    dev = trans.device
     allowed_tok = transform > _THR                       # [B,S,V] on the tensors' device
-    ntok = allowed_tok.sum(-1).cpu().numpy()             # [B,S]
-    tok = transform.argmax(-1).cpu().numpy()             # [B,S] (the token of a one-hot row)
-    tokw = transform.max(-1).values.cpu().numpy()
+    ntok = allowed_tok.sum(-1)                           # [B,S]
+    lens_h = trans_lengths.cpu().numpy().astype(np.int64)
+    for b in range(B):
+        if lens_h[b] < 1 or lens_h[b] > S:
+            raise ValueError(f"trans_lengths[{b}] = {int(lens_h[b])} out of range for S = {S}")
+    if bool((ntok > 1).any()):
+        return _matrices_to_fsa_multi(trans, lens_h, transform, allowed_tok)
+    tr = trans.detach().to(torch.float32)
+    lens = trans_lengths.to(device=dev, dtype=torch.long)
+    ar = torch.arange(S, device=dev)
+    valid = ar[None, :] < lens[:, None]                  # [B,S] states of the machine
+    tokw, tok = transform.detach().to(torch.float32).max(-1)   # [B,S]: weight and id of the row's token
+    bidx = torch.arange(B, device=dev)
+    # emitting arcs j -> i, indexed [b, j, i] so that nonzero() lists them by source state
+    em = ((tr > _THR) & valid[:, :, None] & valid[:, None, :] & (ntok >= 1)[:, :, None]).transpose(1, 2)
+    w_em = (tr + tokw[:, :, None]).transpose(1, 2)
+    fin_row = tr[bidx, lens - 1]                         # [B, j] = trans[b, end, j]
+    fin = (fin_row > _THR) & valid
+    idx = torch.cat([em, fin[:, :, None]], 2).nonzero()  # [n, 3] = (b, j, d), d == S: the final arc
+    ab, aj, ad = idx[:, 0], idx[:, 1], idx[:, 2]
+    is_fin = ad == S
+    adc = ad.clamp(max=S - 1)
+    w = torch.where(is_fin, fin_row[ab, aj], w_em[ab, aj, adc])
+    arcs = torch.stack([aj, torch.where(is_fin, lens[ab], ad), torch.where(is_fin, torch.full_like(ad, -1), tok[ab, adc]),
+                        w.view(torch.int32).to(torch.long)], 1).to(torch.int32)
+    counts = torch.bincount(ab, minlength=B)
+    host = torch.cat([arcs.reshape(-1), counts.to(torch.int32)]).cpu().numpy()     # the one device -> host copy
+    cnt = host[-B:].astype(np.int64)
+    if (cnt == 0).any():
+        raise ValueError(f"utterance {int(np.nonzero(cnt == 0)[0][0])}: the state machine has no allowed transition")
+    off = np.zeros(B + 1, dtype=np.int32)
+    np.cumsum(cnt, out=off[1:])
+    return Fsa(host[:-B].reshape(-1, 4), None, off, (lens_h + 1).astype(np.int32))
+
+
+def _matrices_to_fsa_multi(trans, lens, transform, allowed_tok):
+    """Rows of ``transform`` with several allowed tokens: one arc per (j, i, token), per-utterance on the host."""
+    B, S, _ = trans.shape
+    ntok = allowed_tok.sum(-1).cpu().numpy()
     tr = trans.detach().to(torch.float32).cpu().numpy()
-    lens = trans_lengths.cpu().numpy().astype(np.int64)
-    multi = (ntok > 1).any()
     fsas = []
     for b in range(B):
         Sb = int(lens[b])
-        if Sb < 1 or Sb > S:
-            raise ValueError(f"trans_lengths[{b}] = {Sb} out of range for S = {S}")
         t = tr[b, :Sb, :Sb]
         ii, jj = np.nonzero(t > _THR)                    # transition j -> i
         emits = ntok[b, ii] >= 1
         ii, jj = ii[emits], jj[emits]
-        if multi:
-            rows = []
-            at = allowed_tok[b].cpu().numpy()
-            tf = transform[b].detach().cpu().numpy()
-            for i, j in zip(ii, jj):
-                for c in np.nonzero(at[i])[0]:
-                    rows.append((j, i, c, t[i, j] + tf[i, c]))
-            arcs_e = np.array(rows, dtype=np.float64).reshape(-1, 4)
-            src, dst, lab, w = (arcs_e[:, 0].astype(np.int32), arcs_e[:, 1].astype(np.int32),
-                                arcs_e[:, 2].astype(np.int32), arcs_e[:, 3].astype(np.float32))
-        else:
-            src, dst = jj.astype(np.int32), ii.astype(np.int32)
-            lab = tok[b, ii].astype(np.int32)
-            w = (t[ii, jj] + tokw[b, ii]).astype(np.float32)
+        rows = []
+        at = allowed_tok[b].cpu().numpy()
+        tf = transform[b].detach().cpu().numpy()
+        for i, j in zip(ii, jj):
+            for c in np.nonzero(at[i])[0]:
+                rows.append((j, i, c, t[i, j] + tf[i, c]))
+        arcs_e = np.array(rows, dtype=np.float64).reshape(-1, 4)
+        src, dst, lab, w = (arcs_e[:, 0].astype(np.int32), arcs_e[:, 1].astype(np.int32),
+                            arcs_e[:, 2].astype(np.int32), arcs_e[:, 3].astype(np.float32))
         end = Sb - 1
         fj = np.nonzero(t[end, :] > _THR)[0].astype(np.int32)
         fsrc, fdst = fj, np.full(fj.size, Sb, dtype=np.int32)
