@@ -564,12 +564,12 @@ def viterbi_bench(dev, S, B=8, T=500, V=5001, reps=3):
                     "includes the host-side label extraction of wf.best_path"}
 
 
-def search_bench(dev, S, B=8, T=500, V=5001, beam=20.0, max_active=10000, reps=3):
+def search_bench(dev, S, B=8, T=500, V=5001, beam=20.0, max_active=10000, reps=3, peak=10.0):
     """cfg5 with the beam-pruned search (wf_search; the reference's k2.get_lattice(search_beam=20) at
     utils/lattice_analysis.py:125) beside the exact sweep, on the PEAKED posterior of synth.cfg5_workload (a beam has
     nothing to hold on to in noise); `same_path`: the pruned best path equals the exact one for every utterance."""
     from waterfall_amd.synth import cfg5_workload
-    g, fsa, lp, dense = cfg5_workload(dev, S, B, T, V, peaked=True)
+    g, fsa, lp, dense = cfg5_workload(dev, S, B, T, V, peaked=True, peak=peak)
 
     def timed(f):
         f()
@@ -586,9 +586,14 @@ def search_bench(dev, S, B=8, T=500, V=5001, beam=20.0, max_active=10000, reps=3
             "speedup_vs_exact": ms_exact / ms, "same_path": bool(torch.equal(out["arcs"], exact["arcs"])),
             "same_score": bool(torch.equal(out["scores"], exact["scores"])),
             "mean_active_states": float(out2["n_active"].float().mean().item()),
-            "checked_by": "tests/test_search.py (infinite beam == exact sweep bit for bit; finite beams == oracle.beam_search)",
+            "max_active_states_seen": int(out2["n_active"].max().item()),
+            "planted_label_logit_boost": peak,
+            "checked_by": "tests/test_search.py (infinite beam == exact sweep bit for bit; finite beams == oracle.beam_search; "
+                          "every test on search_kernel and on search_mw_kernel)",
             "desc": f"cfg5 beam-pruned search, S={S} A={fsa.arcs.shape[0]}, B={B}, T={T}, V={V}, search_beam={beam}, "
-                    f"max_active_states={max_active}, peaked synthetic posterior; wall time of wf.pruned_search incl. host"}
+                    f"max_active_states={max_active}, synthetic posterior with the planted path's logit boosted by {peak} "
+                    "(10: a confident model, ~30 active states; 2.6 / 2.3 / 2.0: ~740 / 2 000 / 5 000 active); wall time of "
+                    "wf.pruned_search incl. host"}
 
 
 def ctc_matrices(targets, V, dev):
@@ -949,6 +954,14 @@ def main():
                     others["cfg5_viterbi_S%.0e" % S] = viterbi_bench(dev, S)
                 except Exception as e:   # noqa: BLE001
                     others["cfg5_viterbi_S%.0e" % S] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            # the search where real decoding sits: 10^3 - 10^4 active states (the posterior's peakedness sets the count)
+            for peak, key in ((2.6, "cfg5_search_S1e+06_beam20_active740"), (2.3, "cfg5_search_S1e+06_beam20_active2000"),
+                              (2.0, "cfg5_search_S1e+06_beam20_active5000")):
+                try:
+                    others[key] = search_bench(dev, 1_000_000, peak=peak)
+                except Exception as e:   # noqa: BLE001
+                    others[key] = {"error": repr(e)}
                 torch.cuda.empty_cache()
             try:
                 others["cfg5_search_S1e+06_beam20"] = search_bench(dev, 1_000_000)

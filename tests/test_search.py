@@ -19,6 +19,28 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 INF = float("inf")
 
+# Every test of this file runs on each search kernel: search_kernel (one workgroup per utterance), search_mw_kernel with
+# four workgroups per utterance and every frame of >= 2 survivors shared between them (the graphs here are small: the
+# default would run most frames on workgroup 0 alone), and what wf_search picks by itself.
+VARIANTS = {"one_workgroup": {"WF_SEARCH_WGS": "1"},
+            "four_workgroups_every_frame_shared": {"WF_SEARCH_WGS": "4", "WF_SEARCH_SOLO_MAX": "2"},
+            "default": {}}
+
+
+@pytest.fixture(autouse=True, params=sorted(VARIANTS))
+def search_kernel_variant(request):
+    import os
+    env = VARIANTS[request.param]
+    old = {k: os.environ.get(k) for k in ("WF_SEARCH_WGS", "WF_SEARCH_SOLO_MAX")}
+    for k in old:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    yield request.param
+    for k, v in old.items():
+        os.environ.pop(k, None)
+        if v is not None:
+            os.environ[k] = v
+
 
 def _case(topo, den, seed=50, B=4, T=50):
     c = util.random_case(seed, topo, B=B, T=T, L=7, P=8, den=den)

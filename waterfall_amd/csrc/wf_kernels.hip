@@ -4332,6 +4332,27 @@ struct SearchArgs {
     int tot_double;
     int32_t* n_active;           // [B][Tmax+1] or null
     int prof;                    // measurement aid (WF_SEARCH_PROFILE=1): workgroup 0 prints the cycles of its phases
+    // search_mw_kernel: `wgs` workgroups per utterance
+    int wgs, B, solo_max;
+    struct SearchCtl* ctl;       // [B], zeroed before the launch
+    const int32_t* redo;         // search_kernel after search_mw_kernel: [B] stride of SearchCtl, run only the utterances whose flag is set
+    int redo_stride;
+};
+
+// Per-utterance control block of search_mw_kernel (device memory, zero at launch): the barrier counter of the utterance's
+// workgroups, the abort flag, the frame's counters in three generations (frame t uses c[t % 3] and zeroes c[(t + 1) % 3],
+// while c[(t - 1) % 3] is still being read) and the histogram of the second compaction.
+struct SearchCtl {
+    unsigned bar;
+    int abort;
+    // workgroup 0 -> the utterance's other workgroups, after frames it ran alone: the frame at which they join again (INT_MAX:
+    // never) and the loop state they continue with
+    int resume_t, r_nx;
+    long long r_base, r_base_prev;
+    unsigned r_g;
+    int pad;
+    struct Gen { int ncand; unsigned fmax; int nsurv1, nsurv2; unsigned smin, G1, G2; int pad; } c[3];
+    int hist[1024];
 };
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -4359,21 +4380,23 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
     __shared__ unsigned long long s_fin;
     __shared__ double s_lsum;
     const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.redo && !p.redo[(size_t)u * p.redo_stride]) return;   // (after search_mw_kernel: only what it gave up on)
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int64_t* R = p.tab + (int64_t)u * WF_SR_WORDS;
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
     const int T = (int)U[WF_U_T];
     const int direct = I[WF_I_DIRECT];
     const int32_t* off = p.blob + I[WF_I_OUT_OFF];
-    const int32_t* dst = p.blob + I[WF_I_OUT_DST];
-    const int32_t* col = p.blob + I[WF_I_OUT_COL];
-    const float* w = (const float*)(p.blob + I[WF_I_OUT_W]);
     const int4* orec = (const int4*)(p.blob + I[WF_I_OUT_REC]);
     const int32_t* labels = p.blob + I[WF_I_LABELS];
     const int64_t soff = R[WF_SR_SOFF];
     const int cap = (int)R[WF_SR_CAP];
     unsigned long long* best = p.best + soff;
     double* lsum = p.lsum ? p.lsum + soff : nullptr;
+    if (p.redo) {   // the run that was given up left values behind
+        for (int i = tid; i < I[WF_I_S]; i += kSearchThreads) { best[i] = 0ull; if (lsum) lsum[i] = 0.0; }
+        __syncthreads();
+    }
     int32_t* cand = p.cand + soff;
     unsigned long long* cpk = p.cpk + soff;    // packed best of every candidate, kept while best[] is being reset
     double* cls = p.lsum ? p.cls + soff : nullptr;
@@ -4708,6 +4731,420 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
             const int abase = I[WF_I_ARC_BASE];
             out[T] = abase + fa;
             int64_t r = ld_fresh(slotT + asrc[fa]);
+            for (int t = T - 1; t >= 0; --t) {
+                const int2 rec = arena[r];
+                out[t] = abase + rec.x;
+                r = rec.y;
+            }
+            if (lsum && s_fmax) totl = (double)ord2f(s_fmax) + log(s_lsum);
+        }
+        if (p.tot_log) {
+            if (p.tot_double) ((double*)p.tot_log)[u] = totl;
+            else ((float*)p.tot_log)[u] = (float)totl;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// search_mw_kernel: the same search with SEVERAL workgroups per utterance (wf_search picks it when the chip has room:
+// B x wgs workgroups, all resident).  One workgroup's memory pipeline is what bounds search_kernel at 10^3 - 10^4
+// active states (a frame is ~10 scattered cache lines per active state, dealt with by one CU); here the frame's
+// survivors are dealt to `wgs` workgroups (contiguous blocks), every workgroup expands its block with the same atomics
+// on best[], keeps the candidates IT touched first in a list of its own and compacts that list itself; survivor slots
+// come from one global counter.  The utterance's workgroups meet at a barrier in device memory (a monotonic counter)
+// twice per frame (after the expansion: every tropical value is final; after the compaction: the next frame's
+// survivors are complete), four times when the histogram moves the cut-off.  Frames with fewer than solo_max
+// survivors are run by workgroup 0 alone and cost the others one barrier.
+//
+// Every wait is bounded: a workgroup that has waited ~0.1 s (its partners are not running: the chip is shared with
+// other work and they did not fit) raises the utterance's abort flag, everyone leaves, and wf_search's second launch
+// (search_kernel with `redo`) runs that utterance with one workgroup.  Workgroup b serves utterance b % B: consecutive
+// workgroup ids go round the XCDs, so an utterance's workgroups share an L2 when B is a multiple of 8.
+// ------------------------------------------------------------------------------------------
+constexpr long kSearchSpinLimit = 200000;   // polls of the barrier counter (>= 0.5 us each) before giving up
+
+__global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p) {
+    __shared__ int s_ncand, s_keepbin, s_narcs, s_abort, s_resume;
+    __shared__ uint32_t s_fmax;
+    __shared__ SearchCtl::Gen s_gen;        // the frame's counters while workgroup 0 runs the frame alone
+    __shared__ int s_pfx[kSearchXL];
+    __shared__ int s_xa0[kSearchXL];
+    __shared__ float s_xv[kSearchXL];
+    __shared__ int s_cand[kSearchCL];
+    __shared__ int s_hist[kSearchBins];
+    __shared__ int s_wsum[16];
+    __shared__ unsigned long long s_fin;
+    __shared__ double s_lsum;
+    const int NW = p.wgs;
+    const int u = blockIdx.x % p.B, g = blockIdx.x / p.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int64_t* R = p.tab + (int64_t)u * WF_SR_WORDS;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int T = (int)U[WF_U_T];
+    const int direct = I[WF_I_DIRECT];
+    const int32_t* off = p.blob + I[WF_I_OUT_OFF];
+    const int4* orec = (const int4*)(p.blob + I[WF_I_OUT_REC]);
+    const int32_t* labels = p.blob + I[WF_I_LABELS];
+    const int64_t soff = R[WF_SR_SOFF];
+    const int cap = (int)R[WF_SR_CAP];
+    unsigned long long* best = p.best + soff;
+    double* lsum = p.lsum ? p.lsum + soff : nullptr;
+    // this workgroup's own candidate arrays (a state is first touched by exactly one arc, hence listed by one workgroup)
+    int32_t* cand = p.cand + (int64_t)g * p.nstates + soff;
+    unsigned long long* cpk = p.cpk + (int64_t)g * p.nstates + soff;
+    double* cls = p.lsum ? p.cls + (int64_t)g * p.nstates + soff : nullptr;
+    int32_t* slot = p.slot + soff;
+    int32_t* arcown = p.arcown + R[WF_SR_ARCOFF];
+    int32_t* xstate = p.xstate + R[WF_SR_XOFF];
+    float* xscore = p.xscore + R[WF_SR_XOFF];
+    int2* xarcs = p.xarcs + R[WF_SR_XOFF];
+    double* xla = p.xla + R[WF_SR_XOFF];
+    int2* arena = p.arena + R[WF_SR_AOFF];
+    int32_t* out = p.best_arcs + (int64_t)u * (p.Tmax + 1);
+    int32_t* nact = p.n_active ? p.n_active + (int64_t)u * (p.Tmax + 1) : nullptr;
+    SearchCtl* ctl = p.ctl + u;
+    const float* lp0 = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
+    const float ninf = -INFINITY;
+    const int solo_max = max(p.solo_max, 2);
+    unsigned nbar = 0;
+
+    // barrier of the utterance's workgroups; true: the utterance was given up (every lane of every workgroup leaves)
+    auto grid_sync = [&]() -> bool {
+        __syncthreads();   // (this workgroup's memory operations have completed)
+        if (tid == 0) {
+            ++nbar;
+            const unsigned target = nbar * (unsigned)NW;
+            __threadfence();
+            atomicAdd(&ctl->bar, 1u);
+            long spins = 0;
+            bool ab = false;
+            while (ld_fresh(&ctl->bar) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 255) == 0 && (ld_fresh(&ctl->abort) || spins > kSearchSpinLimit)) { ab = true; break; }
+            }
+            if (ab) atomicExch(&ctl->abort, 1);
+            __threadfence();
+            s_abort = ab || ld_fresh(&ctl->abort);
+        }
+        __syncthreads();
+        return s_abort != 0;
+    };
+
+    if (g == 0) {
+        for (int i = tid; i <= p.Tmax; i += kSearchThreads) { out[i] = -1; if (nact) nact[i] = 0; }
+        if (tid == 0) {   // frame 0: the start state (one survivor: workgroup 0 runs the frame alone)
+            xstate[0] = 0; xscore[0] = 0.f; xla[0] = 0.0;
+            xarcs[0] = make_int2(off[0], off[1] - off[0]);
+            arena[0] = make_int2(-1, -1);
+            slot[0] = 0;
+            if (nact) nact[0] = 1;
+        }
+    }
+    int nX = 1;
+    int64_t base = 1, base_prev = 0;
+    bool dead = false;
+    bool lds_valid = false;   // workgroup 0: its LDS holds the survivors' arcs / scores / degrees (it compacted them alone)
+    float G = 0.f;            // max over the survivors of (log-alpha - tropical score): keeps the log pass's terms <= 1
+    __syncthreads();
+    int t = 0;
+    while (t < T) {
+        const bool solo = nX < solo_max || NW == 1;   // (uniform over the utterance's workgroups)
+        if (solo && g != 0) {
+            // Workgroup 0 runs frames with few survivors alone, at the speed of search_kernel (no barrier in device
+            // memory); the others sleep until it publishes the frame at which they are needed again, or the end.
+            // (Workgroup 0 has the lowest id of the utterance: it is resident before any of its waiters.)
+            if (tid == 0) {
+                int r;
+                long spins = 0;
+                while ((r = ld_fresh(&ctl->resume_t)) <= t) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if ((++spins & 255) == 0 && ld_fresh(&ctl->abort)) { r = 0x7fffffff; break; }
+                }
+                __threadfence();
+                s_resume = r;
+            }
+            __syncthreads();
+            const int r = s_resume;
+            if (r >= T) return;   // the utterance ended (or died) in workgroup 0's hands
+            nX = ld_fresh(&ctl->r_nx);
+            base = ld_fresh(&ctl->r_base);
+            base_prev = ld_fresh(&ctl->r_base_prev);
+            G = ord2f(ld_fresh(&ctl->r_g));
+            t = r;
+            __syncthreads();
+            continue;
+        }
+        SearchCtl::Gen* C = solo ? &s_gen : &ctl->c[t % 3];
+        if (g == 0 && tid == 0) {
+            SearchCtl::Gen* Cn = &ctl->c[(t + 1) % 3];   // (last used two frames ago; the next frame's counters)
+            Cn->ncand = 0; Cn->fmax = 0; Cn->nsurv1 = 0; Cn->nsurv2 = 0; Cn->smin = 0xffffffffu; Cn->G1 = 0; Cn->G2 = 0;
+            if (solo) { s_gen.ncand = 0; s_gen.fmax = 0; s_gen.nsurv1 = 0; s_gen.nsurv2 = 0; s_gen.smin = 0xffffffffu; s_gen.G1 = 0; s_gen.G2 = 0; }
+        }
+        const float* erow = lp0 + (int64_t)t * p.strideT;
+        if (tid == 0) { s_ncand = 0; s_fmax = 0; s_keepbin = 0x7fffffff; }
+        const int x0 = solo ? 0 : (int)((long long)nX * g / NW), x1 = solo ? nX : (int)((long long)nX * (g + 1) / NW);
+        const bool in_lds = solo && lds_valid && nX <= kSearchXL;   // (one chunk, and its data is in the LDS already)
+        auto sync_all = [&]() -> bool { if (solo) { __syncthreads(); return false; } return grid_sync(); };
+        // ---------------- expand (as search_kernel, over this workgroup's block of the survivors)
+        uint32_t lmax = 0;
+        for (int log_pass = 0; log_pass < (lsum ? 2 : 1); ++log_pass) {
+            for (int c0 = x0; c0 < x1; c0 += kSearchXL) {
+                const int m = min(kSearchXL, x1 - c0);
+                if (!(log_pass && in_lds)) {   // (one chunk in the LDS: the prefix of the tropical pass is still there)
+                    constexpr int kPer = kSearchXL / kSearchThreads;
+                    int deg[kPer], run = 0;
+                    __syncthreads();   // (the previous chunk's searches are over; frame 0's survivor is written)
+#pragma unroll
+                    for (int k = 0; k < kPer; ++k) {
+                        const int i = tid * kPer + k;
+                        deg[k] = i < m ? (in_lds ? s_pfx[i] : ld_fresh(&xarcs[c0 + i].y)) : 0;
+                        if (!in_lds && i < m) { s_xa0[i] = ld_fresh(&xarcs[c0 + i].x); s_xv[i] = ld_fresh(xscore + c0 + i); }
+                    }
+#pragma unroll
+                    for (int k = 0; k < kPer; ++k) { const int x = deg[k]; deg[k] = run; run += x; }
+                    int v = run;
+                    for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(v, o, 64); if (lane >= o) v += x; }
+                    if (lane == 63) s_wsum[wave] = v;
+                    __syncthreads();
+                    int add = v - run;
+                    for (int k = 0; k < wave; ++k) add += s_wsum[k];
+#pragma unroll
+                    for (int k = 0; k < kPer; ++k) s_pfx[tid * kPer + k] = add + deg[k];
+                    if (tid == kSearchThreads - 1) s_narcs = add + run;
+                }
+                __syncthreads();
+                const int NA = s_narcs;
+                for (int k0 = 0; k0 < NA; k0 += kSearchThreads) {
+                    const int k = k0 + tid;
+                    bool ok = k < NA;
+                    int lo = 0;
+#pragma unroll
+                    for (int st = kSearchXL / 2; st > 0; st >>= 1)
+                        if (lo + st < m && s_pfx[lo + st] <= k) lo += st;
+                    const int q = ok ? k - s_pfx[lo] + s_xa0[lo] : 0;
+                    const int4 rec = orec[q];
+                    const int d = rec.x, ar = rec.w;
+                    const float we = __int_as_float(rec.z) + erow[direct ? rec.y : labels[rec.y]];
+                    if (!log_pass) {
+                        const float sc = s_xv[lo] + we;
+                        ok = ok && sc > ninf;
+                        const uint32_t o = f2ord(sc);
+                        unsigned long long old = 1ull;
+                        if (ok) {
+                            lmax = max(lmax, o);
+                            arcown[ar] = c0 + lo;
+                            old = atomicMax(&best[d], ((unsigned long long)o << 32) | (0xffffffffu - (uint32_t)ar));
+                        }
+                        const bool fresh = old == 0ull;
+                        const unsigned long long mk = __ballot(fresh);
+                        if (fresh) {
+                            const int leader = __ffsll((long long)mk) - 1;
+                            int wb = 0;
+                            if (lane == leader) wb = atomicAdd(&s_ncand, __popcll(mk));
+                            wb = __shfl(wb, leader, 64);
+                            const int idx = wb + __popcll(mk & ((1ull << lane) - 1ull));
+                            if (idx < kSearchCL) s_cand[idx] = d; else cand[idx] = d;
+                        }
+                    } else {
+                        const float tb = ord2f((uint32_t)(ld_fresh(best + d) >> 32));
+                        const double la = ld_fresh(xla + c0 + lo);
+                        if (ok && we > ninf) atomicAdd(&lsum[d], exp(la + (double)we - (double)tb - (double)G));
+                    }
+                }
+            }
+            if (!log_pass) {
+                for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, o, 64));
+                if (lane == 0 && lmax) atomicMax(&s_fmax, lmax);
+                __syncthreads();
+                if (tid == 0) {
+                    if (s_fmax) atomicMax(&C->fmax, s_fmax);
+                    if (s_ncand) atomicAdd(&C->ncand, s_ncand);
+                }
+            }
+            if (sync_all()) return;   // every value of the pass is final, for every workgroup
+        }
+        // ---------------- prune
+        const int n = s_ncand;                     // this workgroup's candidates
+        const int ntot = ld_fresh(&C->ncand);      // the frame's
+        if (ntot > 0) {
+            const float fmax = ord2f(ld_fresh(&C->fmax));
+            float cutoff = fmax - p.beam;
+            float inv_width = 0.f;
+            int keepbin = 0x7fffffff;
+            const int want_min = min(p.min_active, ntot);
+            uint32_t gmax = 0, lmin = 0xffffffffu;
+            auto compact = [&](const bool from_best) __attribute__((always_inline)) {
+                gmax = 0;
+                int* counter = from_best ? &C->nsurv1 : &C->nsurv2;
+                for (int i0 = 0; i0 < n; i0 += kSearchThreads) {
+                    const int i = i0 + tid;
+                    const bool in = i < n;
+                    const int s = !in ? 0 : (i < kSearchCL ? s_cand[i] : ld_fresh(cand + i));
+                    const unsigned long long pk = !in ? 0ull : (from_best ? ld_fresh(best + s) : ld_fresh(cpk + i));
+                    const float sc = ord2f((uint32_t)(pk >> 32));
+                    const bool keep = in && sc >= cutoff &&
+                                      (keepbin == 0x7fffffff || min(kSearchBins - 1, (int)((fmax - sc) * inv_width)) <= keepbin);
+                    if (in) lmin = min(lmin, (uint32_t)(pk >> 32));
+                    double ls = 0.0;
+                    if (lsum && in && (from_best || keep)) ls = from_best ? ld_fresh(lsum + s) : ld_fresh(cls + i);
+                    const int o0 = keep ? off[s] : 0, o1 = keep ? off[s + 1] : 0;
+                    const int ow = keep ? ld_fresh(arcown + (int)(0xffffffffu - (uint32_t)pk)) : 0;
+                    if (from_best && in) {
+                        best[s] = 0ull; cpk[i] = pk;
+                        if (lsum) { lsum[s] = 0.0; cls[i] = ls; }
+                    }
+                    const unsigned long long mk = __ballot(keep);
+                    int wb = 0;
+                    if (lane == 0 && mk) wb = atomicAdd(counter, __popcll(mk));
+                    wb = __shfl(wb, 0, 64);
+                    if (keep) {
+                        const int k = wb + __popcll(mk & ((1ull << lane) - 1ull));
+                        if (k < cap) {
+                            arena[base + k] = make_int2((int)(0xffffffffu - (uint32_t)pk), (int)(base_prev + ow));
+                            slot[s] = (int)(base + k);
+                            xstate[k] = s;
+                            xscore[k] = sc;
+                            xarcs[k] = make_int2(o0, o1 - o0);
+                            if (solo && k < kSearchXL) { s_xa0[k] = o0; s_xv[k] = sc; s_pfx[k] = o1 - o0; }
+                            if (lsum) {
+                                const double la = (double)sc + (double)G + log(ls);
+                                xla[k] = la;
+                                gmax = max(gmax, f2ord((float)(la - (double)sc)));
+                            }
+                        }
+                    }
+                }
+                if (lsum) {
+                    for (int o = 32; o > 0; o >>= 1) gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, o, 64));
+                    if (lane == 0 && gmax) atomicMax(from_best ? &C->G1 : &C->G2, gmax);
+                }
+            };
+            compact(true);
+            for (int o = 32; o > 0; o >>= 1) lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, o, 64));
+            if (lane == 0 && lmin != 0xffffffffu) atomicMin(&C->smin, lmin);
+            if (sync_all()) return;
+            const int cnt = ld_fresh(&C->nsurv1);
+            const bool tighten = cnt > cap, loosen = !tighten && cnt < want_min;
+            if (tighten || loosen) {   // (uniform over the utterance's workgroups)
+                if (loosen) cutoff = ninf;
+                const float lo = max(cutoff, ord2f(ld_fresh(&C->smin)));
+                inv_width = fmax > lo ? (float)kSearchBins / (fmax - lo) : 0.f;
+                s_hist[tid] = 0;
+                __syncthreads();
+                if (tid == 0) s_keepbin = tighten ? 0 : kSearchBins - 1;
+                for (int i0 = 0; i0 < n; i0 += kSearchThreads) {
+                    const int i = i0 + tid;
+                    const unsigned long long pk = i < n ? ld_fresh(cpk + i) : 0ull;
+                    const float sc = ord2f((uint32_t)(pk >> 32));
+                    if (pk && sc >= cutoff) atomicAdd(&s_hist[min(kSearchBins - 1, (int)((fmax - sc) * inv_width))], 1);
+                }
+                __syncthreads();
+                if (!solo) {   // the workgroups' histograms meet in device memory
+                    if (s_hist[tid]) atomicAdd(&ctl->hist[tid], s_hist[tid]);
+                    if (grid_sync()) return;
+                }
+                int v = solo ? s_hist[tid] : ld_fresh(&ctl->hist[tid]);
+                for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(v, o, 64); if (lane >= o) v += x; }
+                if (lane == 63) s_wsum[wave] = v;
+                __syncthreads();
+                for (int k = 0; k < wave; ++k) v += s_wsum[k];
+                if (tighten) { if (v <= cap) atomicMax(&s_keepbin, tid); }
+                else { if (v >= want_min) atomicMin(&s_keepbin, tid); }
+                __syncthreads();
+                keepbin = s_keepbin;
+                compact(false);
+                if (!solo) {
+                    if (grid_sync()) return;          // every workgroup has read the histogram and placed its survivors
+                    if (g == 0) ctl->hist[tid] = 0;   // (its next use is behind the barriers of a later frame)
+                } else {
+                    __syncthreads();
+                }
+            }
+        }
+        // ---------------- the next frame's survivors (every workgroup of the frame reads the same counters)
+        {
+            const int n2 = ld_fresh(&C->nsurv2), n1 = ld_fresh(&C->nsurv1), nc = ld_fresh(&C->ncand);
+            const bool second = nc > 0 && (n1 > cap || n1 < min(p.min_active, nc));   // the frame ran its second compaction
+            nX = min(second ? n2 : n1, cap);
+            if (lsum && nX > 0) G = ord2f(ld_fresh(second ? &C->G2 : &C->G1));
+        }
+        __syncthreads();   // (s_gen / s_ncand are rewritten by the next frame)
+        lds_valid = solo && nX <= kSearchXL;
+        if (g == 0 && tid == 0 && nact) nact[t + 1] = nX;
+        base_prev = base;
+        base += nX;
+        ++t;
+        if (nX == 0) dead = true;
+        if (solo && NW > 1) {
+            // workgroup 0 after a frame of its own: call the others back when the next frame is theirs too, or send them home
+            const bool over = dead || t >= T;
+            if (over || nX >= solo_max) {
+                if (tid == 0) {
+                    ctl->r_nx = nX; ctl->r_base = base; ctl->r_base_prev = base_prev; ctl->r_g = f2ord(G);
+                }
+                __syncthreads();   // (every lane's stores of the solo frames have completed)
+                if (tid == 0) {
+                    __threadfence();
+                    atomicExch(&ctl->resume_t, over ? 0x7fffffff : t);
+                }
+            }
+        }
+        if (dead) break;
+    }
+    if (g != 0) return;
+    // ---------------- final arcs over the survivors of frame T (workgroup 0)
+    const int NF = I[WF_I_NF];
+    const int32_t* fsrc = p.blob + I[WF_I_FIN_SRC];
+    const float* fw = (const float*)(p.blob + I[WF_I_FIN_W]);
+    const int32_t* farc = p.blob + I[WF_I_FIN_ARC];
+    if (tid == 0) { s_fin = 0ull; s_fmax = 0; s_lsum = 0.0; }
+    __syncthreads();
+    const int32_t* asrc = p.blob + I[WF_I_ARC_SRC];
+    const int64_t baseT = base - nX;
+    auto survivor = [&](int s) -> int {
+        const int64_t r = (int64_t)ld_fresh(slot + s) - baseT;
+        if (r < 0 || r >= nX) return -1;
+        return ld_fresh(xstate + r) == s ? (int)r : -1;
+    };
+    if (!dead) {
+        unsigned long long fb = 0ull;
+        uint32_t lm = 0;
+        for (int i = tid; i < NF; i += kSearchThreads) {
+            const int j = survivor(fsrc[i]);
+            if (j < 0) continue;
+            const float v = ld_fresh(xscore + j) + fw[i];
+            if (!(v > ninf)) continue;
+            fb = max(fb, ((unsigned long long)f2ord(v) << 32) | (0xffffffffu - (uint32_t)farc[i]));
+            if (lsum) lm = max(lm, f2ord((float)(ld_fresh(xla + j) + (double)fw[i])));
+        }
+        if (fb) atomicMax(&s_fin, fb);
+        if (lm) atomicMax(&s_fmax, lm);
+        __syncthreads();
+        if (lsum && s_fmax) {
+            const double ref = (double)ord2f(s_fmax);
+            double acc = 0.0;
+            for (int i = tid; i < NF; i += kSearchThreads) {
+                const int j = survivor(fsrc[i]);
+                if (j < 0 || !(fw[i] > ninf)) continue;
+                acc += exp(ld_fresh(xla + j) + (double)fw[i] - ref);
+            }
+            acc = wave_sum_d(acc);
+            if (lane == 0 && acc != 0.0) atomicAdd(&s_lsum, acc);
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        const unsigned long long fb = dead ? 0ull : s_fin;
+        double totl = -INFINITY;
+        if (fb == 0ull) {
+            p.best_score[u] = ninf;
+        } else {
+            p.best_score[u] = ord2f((uint32_t)(fb >> 32));
+            const int fa = (int)(0xffffffffu - (uint32_t)fb);
+            const int abase = I[WF_I_ARC_BASE];
+            out[T] = abase + fa;
+            int64_t r = ld_fresh(slot + asrc[fa]);
             for (int t = T - 1; t >= 0; --t) {
                 const int2 rec = arena[r];
                 out[t] = abase + rec.x;
@@ -6527,9 +6964,26 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
 namespace {
 struct SearchPlan {
     Plan P;   // only P.utt (utterance table followed by the search table) and P.off_utt are used
-    size_t off_best = 0, off_lsum = 0, off_slot = 0, off_cand = 0, off_cpk = 0, off_cls = 0, off_arcown = 0, off_xs = 0, off_xv = 0, off_xl = 0, off_xa = 0, off_arena = 0, total = 0;
+    size_t off_best = 0, off_lsum = 0, off_slot = 0, off_cand = 0, off_cpk = 0, off_cls = 0, off_arcown = 0, off_xs = 0, off_xv = 0, off_xl = 0, off_xa = 0, off_arena = 0, off_ctl = 0, total = 0;
     int64_t nstates = 0;
+    int wgs = 1;
 };
+// Workgroups per utterance (search_mw_kernel when > 1): up to 8 while the launch fills at most half of the chip, and only
+// where the active set may grow past what one workgroup handles well.  WF_SEARCH_WGS forces a number (1: search_kernel).
+int search_wgs(int B, int max_active) {
+    const int forced = env_int("WF_SEARCH_WGS", 0);
+    if (forced > 0) return std::min(forced, 16);
+    if (max_active > 0 && max_active < 1024) return 1;
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? n : 0;
+        (void)hipGetLastError();
+    }
+    int g = 8;
+    while (g > 1 && (long long)B * g > cus / 2) g >>= 1;
+    return g;
+}
 int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V, int max_active,
                 bool logsum, SearchPlan* S) {
     int rc = check_blob(graph_host);
@@ -6561,14 +7015,16 @@ int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* s
         nr += (int64_t)(T + 1) * cap + 1;
     }
     S->nstates = ns;
+    const size_t W = (size_t)(S->wgs = search_wgs(B, max_active));   // (every workgroup of an utterance lists its own candidates)
     size_t o = 0;
     S->P.off_utt = o; o = align_up(o + sizeof(int64_t) * S->P.utt.size(), 256);
+    S->off_ctl = o; o = align_up(o + sizeof(SearchCtl) * (size_t)B, 256);
     S->off_best = o; o = align_up(o + 8 * (size_t)ns, 256);
     S->off_lsum = o; if (logsum) o = align_up(o + 8 * (size_t)ns, 256);
     S->off_slot = o; o = align_up(o + 4 * (size_t)ns, 256);
-    S->off_cand = o; o = align_up(o + 4 * (size_t)ns, 256);
-    S->off_cpk = o; o = align_up(o + 8 * (size_t)ns, 256);
-    S->off_cls = o; if (logsum) o = align_up(o + 8 * (size_t)ns, 256);
+    S->off_cand = o; o = align_up(o + 4 * (size_t)ns * W, 256);
+    S->off_cpk = o; o = align_up(o + 8 * (size_t)ns * W, 256);
+    S->off_cls = o; if (logsum) o = align_up(o + 8 * (size_t)ns * W, 256);
     S->off_arcown = o; o = align_up(o + 4 * (size_t)na, 256);
     S->off_xs = o; o = align_up(o + 4 * (size_t)nx, 256);
     S->off_xv = o; o = align_up(o + 4 * (size_t)nx, 256);
@@ -6634,6 +7090,16 @@ extern "C" int wf_search(const void* graph_host, const void* graph_dev, const in
     a.n_active = n_active;
     static const int search_prof = getenv("WF_SEARCH_PROFILE") ? atoi(getenv("WF_SEARCH_PROFILE")) : 0;
     a.prof = search_prof;
+    if (S.wgs > 1) {
+        // several workgroups per utterance; what they give up on (their partners never arrived: a chip shared with other
+        // work) the one-workgroup kernel redoes in the second launch, which otherwise exits at once
+        HIP_TRY(hipMemsetAsync(ws + S.off_ctl, 0, sizeof(SearchCtl) * (size_t)B, st));
+        a.wgs = S.wgs; a.B = B; a.solo_max = env_int("WF_SEARCH_SOLO_MAX", 256);
+        a.ctl = (SearchCtl*)(ws + S.off_ctl);
+        hipLaunchKernelGGL(search_mw_kernel, dim3(B * S.wgs), dim3(kSearchThreads), 0, st, a);
+        a.redo = &a.ctl[0].abort;
+        a.redo_stride = (int)(sizeof(SearchCtl) / sizeof(int32_t));
+    }
     hipLaunchKernelGGL(search_kernel, dim3(B), dim3(kSearchThreads), 0, st, a);
     HIP_TRY(hipGetLastError());
     return WF_OK;
