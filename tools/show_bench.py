@@ -32,4 +32,6 @@ for line in open(sys.argv[1]):
             print(f"   {k:28s} {v['frames_per_s']:.4g} f/s  {v['ms_per_step']:.4f} ms  (exact {v['exact_ms_per_step']:.4f} ms, x{v['ratio_to_exact']:.2f}; fallbacks {v['fallback_utterances']})")
             continue
         print(f"   {k:28s} {v['frames_per_s']:.4g} f/s  {v['ms_per_step']:.4f} ms  " +
-              " ".join(f"{a}={b*1e3:.1f}us" for a, b in v["kernels_ms"].items() if not isinstance(b, bool)))
+              " ".join(f"{a}={b*1e3:.1f}us" for a, b in v.get("kernels_ms", {}).items() if not isinstance(b, bool)) +
+              (f" graph build {v['graph_build_ms']:.3f} ms" if "graph_build_ms" in v else "") +
+              (f" (float path {v['float_ms_per_step']:.4f} ms)" if "float_ms_per_step" in v else ""))
