@@ -1070,6 +1070,10 @@ HUB_PATHS = {
     "hub_then_fallback": {"WF_NO_LIN_SWEEP": "2", "WF_FORCE_FALLBACK": "1"},
     "hub_check_kernel_then_fallback": {"WF_NO_LIN_SWEEP": "2", "WF_NO_POST_CHECK": "1", "WF_FORCE_FALLBACK": "1"},
     "linbig": {"WF_NO_LIN_SWEEP": "2", "WF_NO_HUB_SWEEP": "1"},
+    # the default cuts the sweeps in four launches (5/8 + 3 x 1/8 of the steps) with the posterior kernel of the ready frames
+    # beside the next one; one launch + the posterior kernel after it, and another cut (utterances below 32 frames are never cut)
+    "hub_single_launch": {"WF_NO_LIN_SWEEP": "2", "WF_NO_HUB_OVERLAP": "1"},
+    "hub_cut_in_sevenths": {"WF_NO_LIN_SWEEP": "2", "WF_HUB_SEGS": "7:4,5,6,7", "WF_HUB_POST_LDS": "0"},
 }
 
 
@@ -1299,3 +1303,19 @@ def test_double_scores_cfg3_size_rtol_1e9(oracle_lib):
     want2 = util.c_oracle_tot_f64(oracle_lib, w.fsa.as_oracle_graphs(), w.lp.cpu().numpy(), w.segs, nthreads=8)
     np.testing.assert_allclose(w.tot.cpu().numpy(), want2, rtol=1e-9)
     assert w.fallbacks(torch.cuda.current_stream().cuda_stream) == 0
+
+
+def test_hub_sweep_in_segments_equals_the_single_launch():
+    # cfg4-shaped denominator, ragged: the cut sweeps (state restored from the rows + hubsave, the total taken at the middle
+    # frame) against one launch per direction -- same rows, totals bit-equal, gradient within the difference of the two
+    # normalisers (fp32 rows at the middle frame vs the fp64 hub value at the end)
+    c = util.random_case(781, "mmictc", B=6, T=200, L=8, P=1200, den=True)
+    run = lambda: fused_logsum(c["fsa"], c["lp"], c["segs"])
+    tot, grad = run()
+    assert LAST_FALLBACKS[0] == 0
+    tot1, grad1 = _with_env({"WF_NO_HUB_OVERLAP": "1"}, run)
+    assert np.array_equal(tot, tot1)
+    np.testing.assert_allclose(grad, grad1, rtol=2e-6, atol=1e-9)
+    tot7, grad7 = _with_env({"WF_HUB_SEGS": "16:9,10,11,12,13,14,15,16"}, run)
+    assert np.array_equal(tot, tot7)
+    np.testing.assert_allclose(grad, grad7, rtol=2e-6, atol=1e-9)

@@ -139,6 +139,11 @@ struct SweepArgs {
     // sweep_hub_kernel, split ring (rows too long for three whole LDS buffers): pitch of the three buffers of a row's
     // front part and of the two buffers of its back part, in floats; 0: `chunk` whole-row buffers of pitch kpad
     int hub_kpf, hub_kpb;
+    // sweep_hub_kernel in segments (fb_logsum_impl: the posterior kernel of the frames both sweeps have passed runs beside
+    // the sweeps' next segment): this launch runs steps [hub_steps(T, seg_n0), hub_steps(T, seg_n1)) of seg_den parts; the
+    // state that is not in the rows (the hub's fp64 value, the cumulative shift, the next shift) waits in hubsave
+    int seg_n0, seg_n1, seg_den;
+    double* hubsave;      // [2B][4]
     // banded path with output_beam pruning: keep-mask words [2 directions][bmask_rows][64] (band_mask_kernel -> the MASK
     // instantiations of sweep_band_kernel), one row per (utterance, frame) in WF_U_ROW0 order
     unsigned long long* bmask;
@@ -1567,6 +1572,20 @@ __host__ __device__ inline void hub_split(int kpf, int kpb, int K, int c0, int c
 }
 
 // PAT: index into kHubPatterns (G = 2), or -1: the pattern is only known at run time.
+// Segments of the hub sweep: after n of den parts a sweep has done hub_steps frame steps (utterances shorter than
+// kHubSegMinT are not cut: their first segment is the whole sweep).  Frame t's posteriors need alpha row t (forward step
+// t - 1) and beta row t + 1 (backward step T - 2 - t): with both sweeps s steps in, frames T - s - 1 .. s are ready.
+constexpr int kHubSegMinT = 32;
+__host__ __device__ inline int hub_steps(int T, int n, int den) {
+    if (n <= 0) return 0;
+    return (n >= den || T < kHubSegMinT) ? T : (int)((long long)T * n / den);
+}
+__device__ inline bool hub_seg_has(int T, int t, int n, int den) {
+    if (n <= 0) return false;
+    const int s_ = hub_steps(T, n, den);
+    return t >= T - s_ - 1 && t <= s_;
+}
+
 template <int G, int NC, int PAT>
 __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
     constexpr int W = G + 1;
@@ -1582,9 +1601,13 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
     const int32_t* blob = p.blob;
     const int32_t* I = blob + WF_HDR_WORDS + fsa * WF_INFO_WORDS;
     const int S = uni(I[WF_I_S]), K = uni(I[WF_I_K]);
-    if (dir == 0 && tid == 0) p.flag_clear[u] = 0;
+    const bool segmented = p.seg_den > 0;
+    const int step0 = segmented ? hub_steps(T, p.seg_n0, p.seg_den) : 0, step1 = segmented ? hub_steps(T, p.seg_n1, p.seg_den) : T;
+    const bool first_seg = !segmented || p.seg_n0 == 0;
+    if (!first_seg && step0 >= step1) return;   // (an utterance that is not cut: its first segment did everything)
+    if (first_seg && dir == 0 && tid == 0) p.flag_clear[u] = 0;
     if (T < uni(I[WF_I_MINLEN])) {   // structurally infeasible: no sweep needed
-        if (dir == 0 && tid == 0) {
+        if (first_seg && dir == 0 && tid == 0) {
             ((float*)p.tot)[u] = -INFINITY;
             p.totd[u] = (double)-INFINITY;
             p.tot2[u] = (double)-INFINITY;
@@ -1647,38 +1670,39 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             float* fbuf = pbuf;
             float* bbuf = pbuf + 3 * (size_t)p.hub_kpf;
             const int nf = nreq_of(Kf);
-            auto front = [&](const int fr) __attribute__((always_inline)) { issue_run(rowp(fr), fbuf + (size_t)(fr % 3) * p.hub_kpf, Kf); };
-            auto back = [&](const int fr) __attribute__((always_inline)) { issue_run(rowp(fr) + Kf, bbuf + (size_t)(fr & 1) * p.hub_kpb, K - Kf); };
-            if (T > 0) { front(0); back(0); }
-            if (T > 1) { front(1); wait_but(nf); } else __builtin_amdgcn_s_waitcnt(0x0f70);
-            __builtin_amdgcn_s_barrier();         // the initial row is stored, frame 0 is staged
-            for (int step = 0; step < T; ++step) {
-                if (step + 1 < T) back(step + 1);
-                if (step + 2 < T) { front(step + 2); wait_but(nf); }
+            // (buffers by the step's number inside this launch's segment: the compute wavefronts count from 0 too)
+            auto front = [&](const int fr) __attribute__((always_inline)) { issue_run(rowp(fr), fbuf + (size_t)((fr - step0) % 3) * p.hub_kpf, Kf); };
+            auto back = [&](const int fr) __attribute__((always_inline)) { issue_run(rowp(fr) + Kf, bbuf + (size_t)((fr - step0) & 1) * p.hub_kpb, K - Kf); };
+            if (step1 > step0) { front(step0); back(step0); }
+            if (step1 > step0 + 1) { front(step0 + 1); wait_but(nf); } else __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();         // the initial row is stored, the segment's first frame is staged
+            for (int step = step0; step < step1; ++step) {
+                if (step + 1 < step1) back(step + 1);
+                if (step + 2 < step1) { front(step + 2); wait_but(nf); }
                 else __builtin_amdgcn_s_waitcnt(0x0f70);
                 if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
             }
             return;
         }
         const int nreq = nreq_of(K);
-        auto issue = [&](const int frame) __attribute__((always_inline)) { issue_run(rowp(frame), pbuf + (size_t)(frame % nb) * kp, K); };
-        if (T > 0) issue(0);
+        auto issue = [&](const int frame) __attribute__((always_inline)) { issue_run(rowp(frame), pbuf + (size_t)((frame - step0) % nb) * kp, K); };
+        if (step1 > step0) issue(step0);
         if (nb == 3) {
             // three row buffers: frame s + 2 is requested at the START of step s (its buffer, frame s - 1's, is free since the
             // last barrier), frame s + 1 -- requested a whole step earlier -- is awaited before the barrier that ends step s:
             // a request has two frame steps to land
-            if (T > 1) { issue(1); wait_but(nreq); } else __builtin_amdgcn_s_waitcnt(0x0f70);
-            __builtin_amdgcn_s_barrier();         // the initial row is stored, frame 0 is staged
-            for (int step = 0; step < T; ++step) {
-                if (step + 2 < T) { issue(step + 2); wait_but(nreq); }
+            if (step1 > step0 + 1) { issue(step0 + 1); wait_but(nreq); } else __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();         // the initial row is stored, the segment's first frame is staged
+            for (int step = step0; step < step1; ++step) {
+                if (step + 2 < step1) { issue(step + 2); wait_but(nreq); }
                 else __builtin_amdgcn_s_waitcnt(0x0f70);
                 if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
             }
         } else {
             __builtin_amdgcn_s_waitcnt(0x0f70);
             __builtin_amdgcn_s_barrier();
-            for (int step = 0; step < T; ++step) {
-                if (step + 1 < T) issue(step + 1);
+            for (int step = step0; step < step1; ++step) {
+                if (step + 1 < step1) issue(step + 1);
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
             }
@@ -1725,7 +1749,9 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
 #pragma unroll
         for (int i = 0; i < G; ++i) a[k][i] = 0.f;
     double h = dir ? exp((double)finw) : 1.0;
-    {
+    double cum = 0.0;
+    int sh0 = 0;
+    if (first_seg) {
         float* row = arena + (int64_t)(dir ? T : 0) * S;
         for (int s2 = tid; s2 < S; s2 += kHubCompute) row[s2] = s2 == 0 ? (float)h : 0.f;
         if (tid == 0) goff[0] = 0.0;
@@ -1733,6 +1759,20 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             double* crow = p.cmax_w + uni(U[WF_U_ROW0]);
             for (int t = tid; t < T; t += kHubCompute) crow[t] = 0.0;
         }
+    } else {
+        // a later segment: the groups' values are the last row the segment before wrote (fp32 registers left as they were),
+        // the rest waits in hubsave
+        const float* row = arena + (int64_t)(dir ? T - step0 : step0) * S;
+#pragma unroll
+        for (int k = 0; k < kHubSlots; ++k) {
+            const int g = tid + k * kHubCompute;
+#pragma unroll
+            for (int i = 0; i < G; ++i) a[k][i] = g < NG ? row[1 + g * G + i] : 0.f;
+        }
+        const double* sv = p.hubsave + (size_t)(2 * u + dir) * 4;
+        h = sv[0];
+        cum = sv[1];
+        sh0 = uni((int)sv[2]);
     }
     // LDS offsets of this lane's emissions inside a row buffer, per owned group and class; a lane without a group in its last
     // slot reads the buffer's pad word (-inf: probability 0), so that its values stay 0 with no masking in the frame loop
@@ -1754,15 +1794,15 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
     // (the DMA pieces end before a buffer's pad word)
     if (tid < nfb) pbuf[(size_t)tid * kpf + kpf - 1] = -INFINITY;
     if (p.hub_kpf > 0 && tid < 2) pbuf[3 * (size_t)kpf + (size_t)tid * kpb + kpb - 1] = -INFINITY;
-    __syncthreads();   // frame 0 is staged
-    double cum = 0.0;
+    __syncthreads();   // the segment's first frame is staged
+    int sh_end = 0;
     // the frame loop, once per direction at compile time (TR: the backward sweep uses the transposed pattern)
     auto frames = [&](const auto tr) __attribute__((always_inline)) {
         constexpr bool TR = decltype(tr)::value;
-        int sh = 0, ib = 0;
-        for (int step = 0; step < T; ++step) {
+        int sh = sh0, ib = 0;
+        for (int step = step0; step < step1; ++step) {
             const float* pc = pbuf + (size_t)ib * kpf;
-            const float* pcb = bbuf + (size_t)(step & 1) * kpb;   // (read by no slot unless the ring is split)
+            const float* pcb = bbuf + (size_t)((step - step0) & 1) * kpb;   // (read by no slot unless the ring is split)
             ib = ib + 1 == nfb ? 0 : ib + 1;
             const int f = TR ? T - 1 - step : step;
             float* srow = arena + ((p.ablate & 1) ? (int64_t)0 : (int64_t)(TR ? f : f + 1) * S);   // (ablate: timing aid)
@@ -1937,17 +1977,65 @@ __global__ void __launch_bounds__(kMaxThreads) sweep_hub_kernel(SweepArgs p) {
             sh = uni(em > 0 ? 1023 - em : 0);   // next row: maximum back to [1, 2)
             if (tid == 0) srow[0] = (float)hn;
         }
+        sh_end = sh;
     };
     if (dir) frames(std::true_type{}); else frames(std::false_type{});
+    if (step1 < T) {   // the next segment continues from here
+        if (tid == 0) {
+            double* sv = p.hubsave + (size_t)(2 * u + dir) * 4;
+            sv[0] = h; sv[1] = cum; sv[2] = (double)sh_end;
+        }
+        return;
+    }
     if (dir == 0 && tid == 0) {
         const double fsum = h * exp((double)finw);
         const bool dead = !(fsum > 0.0);
         const double tot2 = dead ? (double)-INFINITY : log2(fsum) - cum;
         const double tot = dead ? (double)-INFINITY : tot2 * kLn2;
-        p.tot2[u] = tot2;
-        p.ctot2[u] = 0.0;
+        // (a cut utterance: the posterior kernels have been normalising with hub_tot_kernel's tot2 since the sweeps met;
+        // it stays -- unless this end of the sweep says that nothing gets through at all)
+        if (first_seg || dead) { p.tot2[u] = tot2; p.ctot2[u] = 0.0; }
         p.totd[u] = tot;
         ((float*)p.tot)[u] = (float)tot;
+    }
+}
+
+// The total of a cut hub sweep as soon as both directions have passed the middle frame: sum_s alpha_t[s] beta_t[s] (every
+// path crosses exactly one state at time t), from the fp32 rows and their cumulative shifts.  One workgroup per utterance.
+struct HubTotArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const void* alpha;
+    const void* beta;
+    const double* aoff;
+    const double* boff;
+    double* tot2;
+    double* ctot2;
+    int seg_n, seg_den;
+};
+__global__ void __launch_bounds__(256) hub_tot_kernel(HubTotArgs p) {
+    __shared__ double s_part[4];
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int T = (int)U[WF_U_T], S = I[WF_I_S];
+    if (T < kHubSegMinT || T < I[WF_I_MINLEN]) return;   // not cut (its first segment wrote the total) / infeasible
+    const int t = T / 2;   // hub_steps(T, seg_n) >= t >= T - hub_steps(T, seg_n): seg_n / seg_den >= 1/2 + 1/kHubSegMinT
+    const float* arow = (const float*)p.alpha + U[WF_U_ALPHA] + (int64_t)t * S;
+    const float* brow = (const float*)p.beta + U[WF_U_BETA] + (int64_t)t * S;
+    // (the hub and the groups' states: what the sweeps write -- a row's slot of the super-final state is never touched)
+    const int nrow = min(S, 1 + I[WF_I_HUB_NG] * I[WF_I_HUB_G]);
+    double acc = 0.0;
+    for (int s2 = tid; s2 < nrow; s2 += 256) acc = fma((double)arow[s2], (double)brow[s2], acc);
+    acc = wave_sum_d(acc);
+    if ((tid & 63) == 0) s_part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        const double sum = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        // alpha row t came from forward step t - 1, beta row t from backward step T - 1 - t (one shift per step)
+        const double ga = p.aoff[U[WF_U_OFFS] + lin_shift_index(t - 1, 1, 0)], gb = p.boff[U[WF_U_OFFS] + lin_shift_index(T - 1 - t, 1, 0)];
+        p.tot2[u] = sum > 0.0 ? log2(sum) - ga - gb : (double)-INFINITY;
+        p.ctot2[u] = 0.0;
     }
 }
 
@@ -3478,6 +3566,10 @@ struct PostArgs {
     int32_t* flag_w;
     int force;  // test hook (WF_FORCE_FALLBACK): pass 0 flags every utterance
     int accum;  // WF_ACCUMULATE (post_small_kernel): the posteriors are added to what the rows hold
+    // post_hub_kernel beside a cut hub sweep: this launch computes the frames that are ready after hseg_n of hseg_den parts
+    // of both sweeps and were not after hseg_prev (0: none before); the last launch (hseg_n == hseg_den) also zeroes the rows
+    // nobody computes.  hseg_den == 0: every frame.
+    int hseg_n, hseg_prev, hseg_den;
 };
 
 // log2(v) + add for a scaled probability of the linear sweep (0 -> -inf)
@@ -3789,8 +3881,14 @@ __global__ void __launch_bounds__(256) post_hub_kernel(PostArgs p) {
     const double tot2 = has ? p.tot2[u] : 0.0;
     const int t = f - start;
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
-    if (p.pass == 0 && has && f == 0 && tid == 0 && tot2 == (double)-INFINITY && T >= I[WF_I_MINLEN]) p.flag_w[u] = 1;
+    const bool last_launch = p.hseg_den == 0 || p.hseg_n >= p.hseg_den;
+    if (p.pass == 0 && has && f == 0 && tid == 0 && last_launch && tot2 == (double)-INFINITY && T >= I[WF_I_MINLEN]) p.flag_w[u] = 1;
     if (has && p.pass != 0 && p.flag[u]) return;   // log-domain rows: post_big_kernel's
+    if (p.hseg_den > 0) {
+        if (has && tot2 != (double)-INFINITY && t >= 0 && t < T) {
+            if (!hub_seg_has(T, t, p.hseg_n, p.hseg_den) || hub_seg_has(T, t, p.hseg_prev, p.hseg_den)) return;
+        } else if (!last_launch) return;
+    }
     if (!has || tot2 == (double)-INFINITY || t < 0 || t >= T) {
         zero_span(grow, V, tid, 256);
         return;
@@ -5166,6 +5264,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
     int B = 0;
+    size_t off_hubsave = 0;
     size_t off_utt = 0, off_seq2utt = 0, off_gscale = 0, off_totd = 0, off_tot2 = 0, off_ctot2 = 0, off_flag = 0, off_aoff = 0,
            off_boff = 0, off_E = 0, off_P = 0, off_cmax = 0, off_alpha = 0, off_beta = 0, off_bp = 0, off_finarc = 0, total = 0;
     std::vector<int64_t> utt;  // B * WF_U_WORDS
@@ -5228,7 +5327,7 @@ constexpr int kBigMinStates = 0x7fffffff;   // per-frame launches only where not
 struct Hooks {
     int no_band, no_gen, no_lin, no_linbig, no_reg, no_wave, no_fwd_via_fb, no_gather_small, no_post_small, no_overlap,
         zero_memset, zero_blocks, force_fallback, big_min_s, no_shared_big, post_big_min_s, sweep_ablate, no_arc_cache, no_pruned_fast,
-        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern, no_tab_kernarg, no_hub_split, hub_force_split, no_dbl_fast;
+        post_profile, sweep_profile, quad_r, no_post_check, fill_side_stream, no_hub, no_hub_pattern, no_tab_kernarg, no_hub_split, hub_force_split, no_dbl_fast, no_hub_overlap;
 };
 Hooks g_hooks;
 bool g_hooks_loaded = false;
@@ -5254,6 +5353,7 @@ void load_hooks() {
     h.no_tab_kernarg = env_int("WF_NO_TAB_KERNARG", 0); h.no_hub_split = env_int("WF_NO_HUB_SPLIT", 0);
     h.hub_force_split = env_int("WF_HUB_FORCE_SPLIT", 0);
     h.no_dbl_fast = env_int("WF_NO_DOUBLE_FAST", 0);
+    h.no_hub_overlap = env_int("WF_NO_HUB_OVERLAP", 0);
     h.no_pruned_fast = env_int("WF_NO_PRUNED_FAST", 0);
     g_hooks = h;
     g_hooks_loaded = true;
@@ -5387,6 +5487,7 @@ int make_plan(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg
     P->off_gscale = o; o = align_up(o + sizeof(float) * B, 256);
     P->off_finarc = o; o = align_up(o + sizeof(int32_t) * B, 256);
     P->off_totd = o; o = align_up(o + sizeof(double) * B, 256);
+    P->off_hubsave = o; o = align_up(o + sizeof(double) * 8 * (size_t)B, 256);
     P->off_tot2 = o; o = align_up(o + sizeof(double) * B, 256);
     P->off_E = o; o = align_up(o + sizeof(float) * (size_t)nE, 256);
     if (mode == 0) {
@@ -6178,8 +6279,10 @@ int launch_zero(float* grad, int64_t strideB, int64_t strideT, int num_seqs, int
 // pass: PostArgs::pass (-1: check_kernel ran before; 0: post_small_kernel checks the rows itself)
 int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const float* lp,
                 int64_t strideB, int64_t strideT, int num_seqs, int Tmax, int V, const float* gscale_dev,
-                float* grad, bool skip_zero, hipStream_t st, int pass = -1, bool accum = false) {
+                float* grad, bool skip_zero, hipStream_t st, int pass = -1, bool accum = false, int hseg_n = 0,
+                int hseg_prev = 0, int hseg_den = 0) {
     PostArgs q{};
+    q.hseg_n = hseg_n; q.hseg_prev = hseg_prev; q.hseg_den = hseg_den;
     q.accum = accum ? 1 : 0;
     q.pass = pass; q.flag_w = (int32_t*)(ws + P.off_flag); q.force = hk().force_fallback;
     {
@@ -6208,8 +6311,15 @@ int launch_post(const Plan& P, const void* graph_dev, unsigned char* ws, const f
     // labels (the kernel zeroes the few columns it does not write)
     if (P.hub && pass != 1) {
         const dim3 grid(Tmax, num_seqs);
-#define WF_PHUB_CASE(GG, CC) if (P.hub_g == GG && P.hub_nc == CC) hipLaunchKernelGGL((post_hub_kernel<GG, CC>), grid, dim3(256), 0, st, q)
-        WF_PHUB_CASE(2, 2); else WF_PHUB_CASE(2, 3); else WF_PHUB_CASE(3, 3);
+        // beside a cut sweep (hseg_den > 0, not the last launch): fewer posterior workgroups per CU, so that the sweeps'
+        // LDS-DMA loads are not starved (an LDS request that is never used is the throttle)
+        // (measured on cfg4's mmictc denominator, ms per step by the request: 0 -> 1.52, 32 KB -> 1.50, 64 KB (two workgroups
+        // per CU) -> 1.445, 80 KB and more (one per CU: the posterior kernel falls behind) -> 1.58 = no overlap at all)
+        const size_t plds = (hseg_den > 0 && hseg_n < hseg_den) ? (size_t)env_int("WF_HUB_POST_LDS", 65536) : 0;
+#define WF_PHUB_CASE(GG, CC) if (P.hub_g == GG && P.hub_nc == CC) { \
+            if (plds > 0) { int rc_ = ensure_lds((const void*)post_hub_kernel<GG, CC>, plds); if (rc_) return rc_; } \
+            hipLaunchKernelGGL((post_hub_kernel<GG, CC>), grid, dim3(256), plds, st, q); }
+        WF_PHUB_CASE(2, 2) else WF_PHUB_CASE(2, 3) else WF_PHUB_CASE(3, 3)
         else return wf_fail(WF_EUNSUPPORTED, "internal: no hub posterior kernel for G=%d NC=%d", P.hub_g, P.hub_nc);
 #undef WF_PHUB_CASE
         HIP_TRY(hipGetLastError());
@@ -6431,6 +6541,58 @@ int fb_logsum_impl(const void* graph_host, const void* graph_dev, const int32_t*
             a.bmask = (unsigned long long*)(ws + P.off_bmask); a.bmask_rows = P.n_rows;
         }
         if (g_tm.have_span) a.tspan = g_tm.tspan;
+        if (P.hub && postcheck && !hk().no_hub_overlap && P.Tlong >= kHubSegMinT) {
+            // Hub-form denominators: 2B sweep workgroups leave three quarters of the chip idle, and the posterior kernel
+            // (bandwidth bound, as long as half a sweep) used to wait for both sweeps to finish.  A frame's posteriors need
+            // alpha_t and beta_{t+1} only: once both sweeps are s steps in, frames T - s - 1 .. s are ready.  The sweeps
+            // run in four launches (5/8 of the steps, then three times 1/8: the state that is not in the rows travels
+            // through hubsave); after each, the side stream computes the posterior rows that have become ready -- a
+            // quarter of them each time, beside the sweeps' next eighth.  The total they normalise with comes from the
+            // middle frame as soon as the sweeps have met (hub_tot_kernel).
+            int kSegN[17] = {0, 5, 6, 7, 8}, nseg = 4, den = 8;
+            if (const char* e = getenv("WF_HUB_SEGS")) {   // (tuning aid: "den:n1,n2,...,den")
+                den = atoi(e);
+                nseg = 0;
+                for (const char* q = strchr(e, ':'); q && nseg < 16; q = strchr(q + 1, ',')) kSegN[++nseg] = atoi(q + 1);
+            }
+            if ((rc = side_get(&side, !use_scratch))) return rc;
+            a.hubsave = (double*)(ws + P.off_hubsave);
+            a.seg_den = den;
+            for (int k = 1; k <= nseg; ++k) {
+                a.seg_n0 = kSegN[k - 1]; a.seg_n1 = kSegN[k];
+                if ((rc = launch_sweep_hub(P, a, B, st))) return rc;
+                if (k == 1) {
+                    HubTotArgs ht{a.blob, a.utt, a.alpha, a.beta, a.aoff, a.boff, a.tot2, a.ctot2, kSegN[1], den};
+                    hipLaunchKernelGGL(hub_tot_kernel, dim3(B), dim3(256), 0, st, ht);
+                    HIP_TRY(hipGetLastError());
+                }
+                if (k == nseg && (rc = tm_record(2, st))) return rc;
+                HIP_TRY(hipEventRecord(side->fork, st));
+                HIP_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+                if (k == 1) guard.fork(side->stream, side->join);
+                rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap,
+                                 side->stream, 0, false, kSegN[k], k > 1 ? kSegN[k - 1] : 0, den);
+                if (rc) return rc;
+            }
+            if ((rc = tm_record(3, st))) return rc;
+            if ((rc = guard.wait())) return rc;
+            if ((rc = tm_record(4, st))) return rc;
+            g_tm.have_post = g_tm.on;
+            // what the row check flagged: the workgroup-wide fallback sweep and post_big_kernel (both exit at once otherwise)
+            SweepCfg hc = sweep_config_minimal(P, ab);
+            SweepArgs ha = a;
+            ha.seg_den = 0;
+            ha.flag = (const int32_t*)(ws + P.off_flag);
+            ha.chunk = hc.chunk; ha.kpad = hc.kpad; ha.smax = hc.smax; ha.arcs_lds_words = 0; ha.hcap = hc.hcap;
+            if ((rc = launch_sweep<double, float, M_FB>(hc, ha, B, st))) return rc;
+            rc = launch_post(P, graph_dev, ws, log_probs, strideB, strideT, num_seqs, Tmax, V, grad_scale, grad, overlap, st, 1);
+            if (rc) return rc;
+            if ((rc = tm_record(7, st))) return rc;
+            g_tm.have_fwd = g_tm.on;
+            g_tm.have_check = g_tm.on;
+            g_tm.check_from = 4;
+            return finish();
+        }
         rc = P.hub ? launch_sweep_hub(P, a, B, st) : bs.ok ? launch_sweep_band(bs, a, B, st, nfill, P.pruned_fast) : (lin_config(P).ok ? launch_sweep_lin(lin_config(P), a, B, st) : launch_sweep_linbig(P, a, B, st));
         if (rc) return rc;
         if ((rc = tm_record(2, st))) return rc;
