@@ -672,9 +672,10 @@ def num_den_bench(dev, B=32, T=500, P=5000, L=64, reps=10):
     lp = torch.log_softmax(torch.randn(B, T, V, generator=gen, device=dev) * 3.0, -1).requires_grad_(True)
     seg = torch.tensor([[i, 0, T] for i in range(B)], dtype=torch.int32)
     out = {}
-    for name in ("two_call", "num_den", "two_call_pruned_beam10"):
+    for name in ("two_call", "num_den", "two_call_auto_beam10", "two_call_pruned_beam10"):
         # (the first two in the "exact" beam mode, as the headline; the third with the drop-in's default: output_beam = 10 honoured)
-        wf.set_output_beam_mode("pruned" if "pruned" in name else "exact")
+        # ("auto", the drop-in's default: the numerators' lattice is pruned -- fast path --, the hub-form denominators' is not)
+        wf.set_output_beam_mode("pruned" if "pruned" in name else "auto" if "auto" in name else "exact")
 
         def step():
             lp.grad = None

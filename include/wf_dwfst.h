@@ -243,6 +243,13 @@ int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int3
 int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
                           int32_t B, int32_t num_seqs, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes);
 
+/* *fast = 1 when wf_fb_logsum(flags | WF_PRUNED) keeps these graphs on the fast kernels (the banded path: every topo o
+ * transcript numerator, denominators of <= 64 states), 0 when it takes the masked log-semiring sweeps (hub-form
+ * denominators, graphs beyond the LDS, WF_DOUBLE_ACC).  No counterpart in the reference (k2 has one intersect_dense):
+ * the drop-in's "auto" output_beam mode decides with it.                                                              */
+int wf_fb_pruned_is_fast(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B,
+                         int32_t num_seqs, int32_t V, uint32_t flags, int32_t* fast);
+
 /* ---- log-semiring forward-backward: total scores and gradient (graph.py:61-66 + autograd) ---
  * log_probs: device fp32, element (b,t,v) at b*strideB + t*strideT + v.
  * output_beam: <= 0 or +inf disables pruning (exact sum over all lattice arcs); otherwise (with

@@ -288,11 +288,11 @@ def test_output_beam_default_mode_is_the_reference_semantics():
     """graphloss(..., output_beam=10) (graph.py:81) prunes by default, as k2.intersect_dense(graph, dense, output_beam)
     does (graph.py:61-62); "exact" (what the autouse fixture selects for the parity tests) ignores the beam."""
     from waterfall_amd import graph as g
-    assert g.DEFAULT_BEAM_MODE == "pruned"
+    assert g.DEFAULT_BEAM_MODE == "auto"       # pruned wherever the pruned lattice has a fast path (GPU test: test_pruned.py)
     assert g._BEAM_MODE == "exact" and g._beam_value(10) == 0.0          # inside a test: the fixture's mode
-    wf.set_output_beam_mode(g.DEFAULT_BEAM_MODE)
+    wf.set_output_beam_mode("pruned")
     try:
-        assert g._beam_value(10) == 10.0 and g._beam_value(None) == 0.0
+        assert g._beam_value(10) == 10.0 and g._beam_value(None) == 0.0 and g._beam_value(float("inf")) == 0.0
     finally:
         wf.set_output_beam_mode("exact")
 

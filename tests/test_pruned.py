@@ -115,3 +115,34 @@ def test_pruned_at_baseline_size_against_oracle(topo, P, L, den, beam):
     loss, agrad = autograd_pruned(c["fsa"], c["lp"], c["segs"], beam, True)
     np.testing.assert_allclose(loss, want, rtol=TOT_RTOL, atol=TOT_ATOL)
     np.testing.assert_allclose(agrad, wgrad, atol=GRAD_ATOL)
+
+
+def test_auto_mode_prunes_where_the_fast_path_exists():
+    # the drop-in's default: numerators (banded) honour output_beam, hub-form denominators get the exact sum and one warning
+    import warnings
+    from waterfall_amd import graph as g
+    num = util.random_case(41, "mmictc", B=3, T=40, L=5, P=300)
+    den = util.random_case(41, "mmictc", B=3, T=40, L=5, P=300, den=True)
+
+    def loss_of(c, mode):
+        wf.set_output_beam_mode(mode)
+        try:
+            x = torch.from_numpy(c["lp"]).to(DEV).requires_grad_(True)
+            l = wf.graphloss(c["fsa"], wf.DenseFsaVec(x, torch.from_numpy(c["segs"])), output_beam=4.0, reduction="none")
+            l.sum().backward()
+            return l.detach().cpu().numpy(), x.grad.cpu().numpy()
+        finally:
+            wf.set_output_beam_mode("exact")
+    g._AUTO_WARNED[0] = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        la, ga = loss_of(num, "auto")
+        assert not w                                     # the numerators have the fast pruned path: no warning
+        lp_, gp = loss_of(num, "pruned")
+        le, ge = loss_of(num, "exact")
+        assert np.array_equal(la, lp_) and np.array_equal(ga, gp) and not np.array_equal(la, le)
+        da, dga = loss_of(den, "auto")
+        assert len(w) == 1 and "output_beam" in str(w[0].message)
+        de, dge = loss_of(den, "exact")
+        dp, _ = loss_of(den, "pruned")
+        assert np.array_equal(da, de) and np.array_equal(dga, dge) and not np.array_equal(da, dp)

@@ -66,6 +66,7 @@ _SIGS = {
     "wf_compile_job_wait": (C.c_int, [_i32, _i64]),
     "wf_compile_job_join": (C.c_int, [_i32, _i64, _p]),
     "wf_fb_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, _i32, C.POINTER(_sz)]),
+    "wf_fb_pruned_is_fast": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _u32, C.POINTER(_i32)]),
     "wf_static_scratch_bytes": (C.c_int, [C.POINTER(_sz)]),
     "wf_debug_alloc_count": (C.c_int, [C.POINTER(C.c_int64)]),
     "wf_fb_logsum_static": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _i32, C.c_float, _u32,

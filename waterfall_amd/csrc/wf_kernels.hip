@@ -6122,6 +6122,18 @@ extern "C" int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2
     return WF_OK;
 }
 
+// Does wf_fb_logsum(flags | WF_PRUNED) keep these graphs on the fast (probability-domain, banded) kernels?  The Python
+// drop-in's "auto" beam mode asks before it decides whether output_beam is honoured for a graph vector.
+extern "C" int wf_fb_pruned_is_fast(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B,
+                                    int32_t num_seqs, int32_t V, uint32_t flags, int32_t* fast) {
+    if (!fast) return wf_fail(WF_EINVAL, "wf_fb_pruned_is_fast: null pointer");
+    Plan P;
+    int rc = make_plan(graph_host, utt2fsa, seg, B, V, num_seqs, 8, 0, &P, (flags & WF_DOUBLE_ACC) != 0, true);
+    if (rc) return rc;
+    *fast = P.pruned_fast ? 1 : 0;
+    return WF_OK;
+}
+
 // Test aid: how many utterances of the last wf_fb_logsum call on this workspace were redone by the log-semiring fallback
 // (their probability-domain rows failed the row check, or WF_FORCE_FALLBACK).  Same (graph, seg, V, num_seqs, flags,
 // need_grad) as that call.  Synchronises the stream.

@@ -8,6 +8,7 @@ one_best_decoding + get_aux_labels).
 """
 import ctypes as C
 import math
+import warnings
 
 import numpy as np
 import torch
@@ -293,7 +294,8 @@ def graphloss_num_den(num_graph: Fsa, den_graph: Fsa, dense_fsa_vec: DenseFsaVec
     when the numerator graphs are beyond WF_ACCUMULATE's reach, under the "pruned" beam mode, or without a gradient."""
     assert reduction in ('none', 'mean', 'sum')
     lp = dense_fsa_vec.log_probs
-    fused = (_beam_value(output_beam) == 0.0 and lp.requires_grad and torch.is_grad_enabled() and lp.device.type == "cuda"
+    fused = (_beam_value(output_beam, den_graph, dense_fsa_vec) == 0.0 and _beam_value(output_beam, num_graph, dense_fsa_vec) == 0.0
+             and lp.requires_grad and torch.is_grad_enabled() and lp.device.type == "cuda"
              and isinstance(num_graph, Fsa) and isinstance(den_graph, Fsa) and den_graph.all_direct()
              and num_graph.accumulate_ok(dense_fsa_vec.supervision_segments.numpy(), lp.shape[0], lp.shape[2]))
     if not fused:
@@ -328,19 +330,24 @@ def set_eager_gradient(on: bool):
     _EAGER = bool(on)
 
 
-DEFAULT_BEAM_MODE = "pruned"   # what the reference's own call does: k2.intersect_dense(graph, dense, output_beam)
-_BEAM_MODE = DEFAULT_BEAM_MODE
+DEFAULT_BEAM_MODE = "auto"   # output_beam honoured (the reference's k2.intersect_dense(graph, dense, output_beam)) wherever
+_BEAM_MODE = DEFAULT_BEAM_MODE  # the pruned lattice has a fast path; see set_output_beam_mode
+_AUTO_WARNED = [False]
 
 
 def set_output_beam_mode(mode: str):
     """How `output_beam` (graph.py:61-62 passes it to k2.intersect_dense) is honoured.
 
-    "pruned" (default since round 3): drop lattice arcs whose best path is more than output_beam below the best
-    path (a tropical forward-backward pass, keep masks, then the masked sweeps and posteriors; on
-    banded graphs -- every numerator, the small denominators -- all of it stays on the probability-domain path:
-    2.0x the exact step at cfg3 / cfg2 sizes).  This is the rule the reference's k2.intersect_dense call states
-    (graph.py:61-62, default beam 10 at :81); k2 is not available to pin its arithmetic against ("parity
-    unpinned").  output_beam=None or inf: no pruning.
+    "pruned": drop lattice arcs whose best path is more than output_beam below the best path (a
+    tropical forward-backward pass, keep masks, then the masked sweeps and posteriors; on banded graphs -- every
+    numerator, the small denominators -- all of it stays on the probability-domain path: 2.0x the exact step at
+    cfg3 / cfg2 sizes).  This is the rule the reference's k2.intersect_dense call states (graph.py:61-62, default
+    beam 10 at :81); k2 is not available to pin its arithmetic against ("parity unpinned").
+    output_beam=None or inf: no pruning.  Graphs without that fast path (hub-form denominators: cfg4; graphs beyond
+    the LDS sweeps; use_double_scores) take masked log-semiring sweeps: 33 ms instead of 2 for cfg4's
+    numerator - denominator step.
+    "auto" (the default): "pruned" for the graph vectors that have the fast path (wf_fb_pruned_is_fast), "exact" for
+    the others, with one warning -- the reference's semantics wherever they do not cost an order of magnitude.
     "exact": sum over ALL lattice arcs whatever the beam -- the limit output_beam -> inf, half the cost.  Each
     pruned arc carries < e^-beam of the best path's mass, but an untrained model spreads such arcs over most of
     the lattice: against the oracle's pruned lattice the two modes agree inside the tolerances (1e-4 relative on
@@ -349,14 +356,40 @@ def set_output_beam_mode(mode: str):
     tests/test_gpu_parity.py::test_exact_mode_is_within_tolerance_of_the_reference_beams, INTEGRATION.md).
     """
     global _BEAM_MODE
-    assert mode in ("exact", "pruned")
+    assert mode in ("auto", "exact", "pruned")
     _BEAM_MODE = mode
 
 
-def _beam_value(output_beam):
-    if _BEAM_MODE == "exact" or output_beam is None:
+def _beam_value(output_beam, graph=None, dense=None, use_double_scores=False):
+    """The beam wf_fb_logsum gets (0: no pruning) for this call under the current mode."""
+    if _BEAM_MODE == "exact" or output_beam is None or not (output_beam > 0) or math.isinf(output_beam):
         return 0.0
+    if _BEAM_MODE == "auto":
+        if graph is None or not _pruned_is_fast(graph, dense, use_double_scores):
+            if graph is not None and not _AUTO_WARNED[0]:
+                _AUTO_WARNED[0] = True
+                warnings.warn("waterfall_amd.graphloss: output_beam is not applied to graphs without a fast pruned path "
+                              "(hub-form denominators, graphs beyond the LDS sweeps, use_double_scores): they get the sum "
+                              "over all lattice arcs.  set_output_beam_mode('pruned') applies the beam to every graph "
+                              "(masked log-semiring sweeps, ~15x slower on cfg4's denominators); 'exact' never prunes.")
+            return 0.0
     return float(output_beam)
+
+
+def _pruned_is_fast(graph, dense, use_double_scores):
+    """wf_fb_pruned_is_fast for these graphs, cached on the graph object (the answer depends on the graphs' shapes)."""
+    key = bool(use_double_scores)
+    c = graph.__dict__.setdefault("_pruned_fast_cache", {})
+    v = c.get(key)
+    if v is None:
+        seg = dense.supervision_segments.numpy()
+        lp = dense.log_probs
+        out = C.c_int32(0)
+        _lib.check(_lib.lib().wf_fb_pruned_is_fast(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), seg.shape[0],
+                                                   lp.shape[0], lp.shape[2], _lib.WF_DOUBLE_ACC if use_double_scores else 0,
+                                                   C.byref(out)))
+        v = c[key] = bool(out.value)
+    return v
 
 
 class GraphLoss(nn.Module):
@@ -381,7 +414,7 @@ _EAGER_DIRECT = True   # denominators (direct label columns) take the fused call
 
 def _graphloss(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double_scores, target_lengths):
     """graph.py:61-76: loss = -tot_scores (float32), reduced 'none' | 'sum' | 'mean' (/ target_lengths, then batch mean)."""
-    beam = _beam_value(output_beam)
+    beam = _beam_value(output_beam, decoding_graph if isinstance(decoding_graph, Fsa) else None, dense_fsa_vec, use_double_scores)
     lp = dense_fsa_vec.log_probs
     if (_EAGER and not use_double_scores and lp.requires_grad and torch.is_grad_enabled()
             and isinstance(decoding_graph, Fsa) and (decoding_graph.all_compact() or _EAGER_DIRECT)):
