@@ -224,3 +224,36 @@ def test_random_graphs_with_exact_ties_against_oracle():
     r = subprocess.run([sys.executable, "-u", os.path.join(root, "tools", "fuzz_search.py"), "40", "7", "8000"], cwd=root,
                        capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _fan_graph(n, weights, V):
+    """start --label 1--> n states, each with a self-loop (label 1) and a final arc; arcs sorted by source state."""
+    arcs = [(0, 1 + i, 1, float(weights[i])) for i in range(n)]
+    for i in range(n):
+        arcs.append((1 + i, 1 + i, 1, 0.0))
+        arcs.append((1 + i, n + 1, -1, 0.0))
+    return wf.Fsa.from_arcs(arcs, n + 2)
+
+
+@pytest.mark.parametrize("tied", [True, False])
+def test_max_active_with_more_tied_states_than_fit(tied):
+    # ADVICE r02: the histogram's best bin alone holds more than max_active candidates -- exact ties (tied), or scores a
+    # hair apart while one straggler stretches the histogram's range.  The cut must never drop the frame's best candidate:
+    # the best path and score stay those of the exact search, run after run.
+    n, cap, T, V = 600, 100, 12, 5
+    rng = np.random.default_rng(3)
+    w = np.zeros(n, dtype=np.float32) if tied else (-1e-5 * rng.permutation(n)).astype(np.float32)
+    if not tied:
+        w[-1] = -40.0       # the straggler: bins of 0.04, every other candidate in bin 0
+    fsa = wf.create_fsa_vec([_fan_graph(n, w, V)] * 2).to(DEV)
+    lp = torch.log_softmax(torch.randn(2, T, V, generator=torch.Generator().manual_seed(1)), -1).to(DEV)
+    dense = wf.DenseFsaVec(lp, torch.tensor([[0, 0, T], [1, 0, T - 3]], dtype=torch.int32))
+    exact = wf.best_path(fsa, dense)
+    outs = [wf.pruned_search(fsa, dense, search_beam=INF, min_active_states=0, max_active_states=cap, return_active=True)
+            for _ in range(3)]
+    for out in outs:
+        assert torch.equal(out["scores"], exact["scores"])
+        assert torch.equal(out["arcs"], exact["arcs"])
+        assert int(out["n_active"].max()) <= cap
+    na = outs[0]["n_active"][0, 1:T + 1]
+    assert int(na.min()) >= (cap if tied else cap // 2)      # (not tied: the refined bins cut within a bin of the cap)

@@ -4467,8 +4467,9 @@ template <typename T> __device__ __forceinline__ T ld_fresh(const T* p) {
 }
 
 __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
-    __shared__ int s_ncand, s_nsurv, s_keepbin, s_narcs;
+    __shared__ int s_ncand, s_nsurv, s_keepbin, s_narcs, s_bin0;
     __shared__ uint32_t s_fmax, s_min, s_G;
+    __shared__ unsigned long long s_pkmax;   // the frame's best candidate (score, then lowest arc): kept whatever the cut-off does
     __shared__ int s_pfx[kSearchXL];        // exclusive prefix of the survivors' out-degrees (arc -> owner lookup)
     __shared__ int s_xa0[kSearchXL];        // first outgoing arc and tropical score of the first kSearchXL survivors
     __shared__ float s_xv[kSearchXL];
@@ -4532,7 +4533,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
     if (p.prof) pt0 = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < T; ++t) {
         const float* erow = lp0 + (int64_t)t * p.strideT;
-        if (tid == 0) { s_ncand = 0; s_fmax = 0; s_nsurv = 0; s_min = 0xffffffffu; s_keepbin = 0x7fffffff; }
+        if (tid == 0) { s_ncand = 0; s_fmax = 0; s_nsurv = 0; s_min = 0xffffffffu; s_keepbin = 0x7fffffff; s_pkmax = 0ull; }
         const float G = ord2f(s_G);
         const bool xl = nX <= kSearchXL;   // (uniform) the survivors' arcs / scores are in the LDS
         // ---------------- expand: ARC-parallel.  The survivors' out-degrees are prefix-summed into the LDS (chunks of
@@ -4653,8 +4654,12 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
         // run (from_best) also moves the packed value of every candidate out of best[] / lsum[] (which go back to "empty"
         // for the next frame) into cpk / cls, where a second run with a moved cut-off finds them.
         uint32_t gmax = 0, lmin = 0xffffffffu;
+        bool ovf = false;   // second run only: the best bin alone holds more than cap candidates (exact ties)
+        unsigned long long lpk = 0ull;
         auto compact = [&](const bool from_best) __attribute__((always_inline)) {
             gmax = 0;
+            const unsigned long long pkbest = from_best ? 0ull : s_pkmax;
+            const int lim = ovf ? cap - 1 : cap;   // (ovf: slot cap - 1 belongs to the frame's best candidate)
             for (int i0 = 0; i0 < n; i0 += kSearchUnroll * kSearchThreads) {
                 int s[kSearchUnroll];
                 unsigned long long pk[kSearchUnroll];
@@ -4678,7 +4683,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
                     const float sc = ord2f((uint32_t)(pk[j] >> 32));
                     keep[j] = in[j] && sc >= cutoff &&
                               (keepbin == 0x7fffffff || min(kSearchBins - 1, (int)((fmax - sc) * inv_width)) <= keepbin);
-                    if (in[j]) lmin = min(lmin, (uint32_t)(pk[j] >> 32));
+                    if (in[j]) { lmin = min(lmin, (uint32_t)(pk[j] >> 32)); if (from_best) lpk = max(lpk, pk[j]); }
                     ls[j] = 0.0;
                     if (lsum && in[j] && (from_best || keep[j])) ls[j] = from_best ? ld_fresh(lsum + s[j]) : ld_fresh(cls + i);
                     o0[j] = keep[j] ? off[s[j]] : 0;
@@ -4692,13 +4697,14 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
                         best[s[j]] = 0ull; cpk[i] = pk[j];
                         if (lsum) { lsum[s[j]] = 0.0; cls[i] = ls[j]; }
                     }
-                    const unsigned long long mk = __ballot(keep[j]);   // wave-aggregated append (uniform control flow here)
+                    const bool isbest = ovf && keep[j] && pk[j] == pkbest;
+                    const unsigned long long mk = __ballot(keep[j] && !isbest);   // wave-aggregated append (uniform control flow here)
                     int wb = 0;
                     if (lane == 0 && mk) wb = atomicAdd(&s_nsurv, __popcll(mk));
                     wb = __shfl(wb, 0, 64);
                     if (keep[j]) {
-                        const int k = wb + __popcll(mk & ((1ull << lane) - 1ull));
-                        if (k < cap) {
+                        const int k = isbest ? cap - 1 : wb + __popcll(mk & ((1ull << lane) - 1ull));
+                        if (isbest || k < lim) {
                             const float sc = ord2f((uint32_t)(pk[j] >> 32));
                             arena[base + k] = make_int2((int)(0xffffffffu - (uint32_t)pk[j]), (int)(base_prev + ow[j]));
                             slot[s[j]] = (int)(base + k);
@@ -4721,6 +4727,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
         compact(true);
         for (int o = 32; o > 0; o >>= 1) lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, o, 64));
         if (lane == 0) atomicMin(&s_min, lmin);
+        for (int o = 32; o > 0; o >>= 1) lpk = max(lpk, (unsigned long long)__shfl_xor((long long)lpk, o, 64));
+        if (lane == 0 && lpk) atomicMax(&s_pkmax, lpk);
         __syncthreads();
         const int cnt = s_nsurv;
         const bool tighten = cnt > cap, loosen = !tighten && cnt < want_min;
@@ -4730,33 +4738,44 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
             if (loosen) cutoff = ninf;
             const float lo = max(cutoff, ord2f(s_min));
             inv_width = fmax > lo ? (float)kSearchBins / (fmax - lo) : 0.f;
-            s_hist[tid] = 0;
-            __syncthreads();   // (every lane has read s_nsurv by now; cpk / cls of the first run are visible)
-            if (tid == 0) { s_nsurv = 0; s_keepbin = tighten ? 0 : kSearchBins - 1; }
-            for (int i0 = 0; i0 < n; i0 += kSearchUnroll * kSearchThreads) {
-                unsigned long long pk[kSearchUnroll];
+            // When the best bin alone holds more than cap candidates the histogram is taken again over that bin's range (up
+            // to three times: 2^-30 of the first range); candidates that are still tied then -- equal scores -- are cut in
+            // arrival order, but never the frame's best one (s_pkmax: it takes the last slot).
+            for (int refine = 0;; ++refine) {
+                s_hist[tid] = 0;
+                __syncthreads();   // (every lane has read s_nsurv by now; cpk / cls of the first run are visible)
+                if (tid == 0) { s_nsurv = 0; s_keepbin = tighten ? 0 : kSearchBins - 1; }
+                for (int i0 = 0; i0 < n; i0 += kSearchUnroll * kSearchThreads) {
+                    unsigned long long pk[kSearchUnroll];
 #pragma unroll
-                for (int j = 0; j < kSearchUnroll; ++j) {
-                    const int i = i0 + j * kSearchThreads + tid;
-                    pk[j] = i < n ? ld_fresh(cpk + i) : 0ull;
-                }
+                    for (int j = 0; j < kSearchUnroll; ++j) {
+                        const int i = i0 + j * kSearchThreads + tid;
+                        pk[j] = i < n ? ld_fresh(cpk + i) : 0ull;
+                    }
 #pragma unroll
-                for (int j = 0; j < kSearchUnroll; ++j) {
-                    const float sc = ord2f((uint32_t)(pk[j] >> 32));
-                    if (pk[j] && sc >= cutoff) atomicAdd(&s_hist[min(kSearchBins - 1, (int)((fmax - sc) * inv_width))], 1);
+                    for (int j = 0; j < kSearchUnroll; ++j) {
+                        const float sc = ord2f((uint32_t)(pk[j] >> 32));
+                        if (pk[j] && sc >= cutoff) atomicAdd(&s_hist[min(kSearchBins - 1, (int)((fmax - sc) * inv_width))], 1);
+                    }
                 }
+                __syncthreads();
+                int v = s_hist[tid];   // inclusive scan of the 1024 bins
+                for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(v, o, 64); if (lane >= o) v += x; }
+                if (lane == 63) s_wsum[wave] = v;
+                __syncthreads();
+                for (int k = 0; k < wave; ++k) v += s_wsum[k];
+                if (tid == 0) s_bin0 = v;
+                // tighten: the last bin whose running count still fits; loosen: the first bin that reaches min_active
+                if (tighten) { if (v <= cap) atomicMax(&s_keepbin, tid); }
+                else { if (v >= want_min) atomicMin(&s_keepbin, tid); }
+                __syncthreads();
+                keepbin = s_keepbin;
+                ovf = tighten && keepbin == 0 && s_bin0 > cap;
+                if (!ovf || refine == 3 || !(inv_width > 0.f) || !(inv_width < 1e30f)) break;
+                cutoff = max(cutoff, fmax - 1.f / inv_width);   // the best bin's lower edge
+                inv_width *= (float)kSearchBins;
+                __syncthreads();   // (s_bin0 / s_keepbin are rewritten)
             }
-            __syncthreads();
-            int v = s_hist[tid];   // inclusive scan of the 1024 bins
-            for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(v, o, 64); if (lane >= o) v += x; }
-            if (lane == 63) s_wsum[wave] = v;
-            __syncthreads();
-            for (int k = 0; k < wave; ++k) v += s_wsum[k];
-            // tighten: the last bin whose running count still fits; loosen: the first bin that reaches min_active
-            if (tighten) { if (v <= cap) atomicMax(&s_keepbin, tid); }
-            else { if (v >= want_min) atomicMin(&s_keepbin, tid); }
-            __syncthreads();
-            keepbin = s_keepbin;
             compact(false);
             __syncthreads();
         }
@@ -4766,7 +4785,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
             __syncthreads();
             if (lane == 0 && gmax) atomicMax(&s_G, gmax);
         }
-        nX = min(s_nsurv, cap);
+        nX = ovf ? cap : min(s_nsurv, cap);
         if (tid == 0 && nact) nact[t + 1] = nX;
         base_prev = base;
         base += nX;
@@ -5151,6 +5170,12 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
                 else { if (v >= want_min) atomicMin(&s_keepbin, tid); }
                 __syncthreads();
                 keepbin = s_keepbin;
+                if (tighten && keepbin == 0 && (solo ? s_hist[0] : ld_fresh(&ctl->hist[0])) > cap) {
+                    // the best bin alone overflows (exact ties): search_kernel refines the histogram and keeps the frame's
+                    // best candidate; the utterance goes to it (every workgroup of the frame sees the same bin)
+                    if (tid == 0) atomicExch(&ctl->abort, 1);
+                    return;
+                }
                 compact(false);
                 if (!solo) {
                     if (grid_sync()) return;          // every workgroup has read the histogram and placed its survivors
