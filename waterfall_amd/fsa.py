@@ -232,6 +232,10 @@ class Fsa:
             if self._pending is not None:
                 self._pending.join_stream(device)   # the caller's stream waits for the compile kernels
         if key not in self._blob_dev:
+            if self._pending is not None:
+                # (a device-compiled vector: its host side holds the header words only, the tables exist on that device)
+                raise RuntimeError(f"these graphs were compiled on {self._pending.device}, not {device}: compile them there "
+                                   "(compile_ctc_k2_graphs(..., device=...)) or on the host")
             host = self.blob_host()
             if self._blob_pin is not None:
                 dev = torch.empty(host.size, dtype=torch.int32, device=device)
