@@ -4937,8 +4937,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
             long spins = 0;
             bool ab = false;
             while (ld_fresh(&ctl->bar) < target) {
-                __builtin_amdgcn_s_sleep(2);
-                if ((++spins & 255) == 0 && (ld_fresh(&ctl->abort) || spins > kSearchSpinLimit)) { ab = true; break; }
+                if (++spins > 64) __builtin_amdgcn_s_sleep(2);   // (the partners are usually a round trip or two away)
+                if ((spins & 255) == 0 && (ld_fresh(&ctl->abort) || spins > kSearchSpinLimit)) { ab = true; break; }
             }
             if (ab) atomicExch(&ctl->abort, 1);
             __threadfence();
