@@ -582,14 +582,19 @@ def search_bench(dev, S, B=8, T=500, V=5001, beam=20.0, max_active=10000, reps=3
     ms_exact, exact = timed(lambda: wf.best_path(fsa, dense))
     ms, out = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, max_active, log_tot=False))
     ms_log, out2 = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, max_active, log_tot=True, return_active=True))
-    return {"ms_per_call": ms, "ms_per_call_with_log_total": ms_log, "exact_sweep_ms_per_call": ms_exact,
+    # get_lattice's output_beam (lattice_analysis.sh's lattice_beam = 8): the backward launch over the finished lattice
+    ms_lat, out3 = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, max_active, log_tot=True, output_beam=8.0))
+    return {"ms_per_call": ms, "ms_per_call_with_log_total": ms_log, "ms_per_call_with_output_beam8": ms_lat,
+            "lattice_arcs_per_frame_output_beam8": float(out3["lattice_arcs"].double().mean().item()) / T,
+            "log_total_minus_output_beam8_total": float((out2["tot_log"].double() - out3["tot_log"].double()).mean().item()),
+            "exact_sweep_ms_per_call": ms_exact,
             "speedup_vs_exact": ms_exact / ms, "same_path": bool(torch.equal(out["arcs"], exact["arcs"])),
             "same_score": bool(torch.equal(out["scores"], exact["scores"])),
             "mean_active_states": float(out2["n_active"].float().mean().item()),
             "max_active_states_seen": int(out2["n_active"].max().item()),
             "planted_label_logit_boost": peak,
             "checked_by": "tests/test_search.py (infinite beam == exact sweep bit for bit; finite beams == oracle.beam_search; "
-                          "every test on search_kernel and on search_mw_kernel)",
+                          "output_beam == oracle.lattice_search; every test on search_kernel and on search_mw_kernel)",
             "desc": f"cfg5 beam-pruned search, S={S} A={fsa.arcs.shape[0]}, B={B}, T={T}, V={V}, search_beam={beam}, "
                     f"max_active_states={max_active}, synthetic posterior with the planted path's logit boosted by {peak} "
                     "(10: a confident model, ~30 active states; 2.6 / 2.3 / 2.0: ~740 / 2 000 / 5 000 active); wall time of "

@@ -361,6 +361,22 @@ int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2
               float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
               size_t workspace_bytes, void* stream);
 
+/* The same search followed by get_lattice's output_beam (utils/lattice_analysis.py:125, lattice_beam of lattice_analysis.sh):
+ * one more launch walks the lattice the search left (every arc between a survivor of frame t and a survivor of frame t + 1,
+ * and the final arcs) backwards and keeps the arcs with alpha(src) + score + beta(dst) >= best_score - output_beam (tropical
+ * alpha / beta within that lattice, fp32); tot_log (required; fp32 [B] or fp64 [B] with WF_DOUBLE_ACC) is the log-semiring
+ * total of the lattice that remains -- what lattice.get_tot_scores(True, True) reads at lattice_analysis.py:128 --
+ * lattice_arcs (nullable, device int64 [B]) the number of arcs in it.  best_score / best_arcs / n_active as wf_search
+ * (the best path never depends on output_beam).  output_beam = +inf keeps every arc that lies on a complete path: the total
+ * then equals wf_search's.  The rule is oracle.lattice_search's; k2's own arithmetic is parity unpinned as above.      */
+int wf_search_lattice_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B, int32_t V,
+                                      int32_t max_active_states, size_t* bytes);
+int wf_search_lattice(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
+                      int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
+                      float search_beam, float output_beam, int32_t min_active_states, int32_t max_active_states,
+                      uint32_t flags, float* best_score, int32_t* best_arcs, void* tot_log, int64_t* lattice_arcs,
+                      int32_t* n_active, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- multi-GPU: the buffer of the one fused all-reduce per step (the reference gets these numbers
  * from Lightning's DDP reductions around graph.py:66-76).  out[0] = -(sum of the finite tot[i]), out[1] = n_frames,
  * out[2] = number of infeasible utterances (tot = -inf); device pointers, one small launch on `stream`.            */

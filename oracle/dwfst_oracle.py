@@ -254,14 +254,15 @@ def viterbi(g, lp, T, dtype=np.float32):
 
 
 
-def beam_search(g, lp, T, search_beam=np.inf):
+def beam_search(g, lp, T, search_beam=np.inf, frames=None):
     """Frame-synchronous token passing with a tropical beam: the restatement wf_search is tested against.
     [the role of k2.get_lattice's search at utils/lattice_analysis.py:125; k2's own beam arithmetic is parity unpinned]
 
     A state of frame t survives when its tropical score v satisfies v >= max_t - search_beam (fp32 arithmetic as in
     `viterbi`); only survivors are expanded.  Returns (score, arcs, tot_log, n_active):
     best path over the surviving lattice with the tie rule of `viterbi`, the log-semiring total (fp64) over all paths
-    through surviving states, and the survivor count per frame (t = 0..T).
+    through surviving states, and the survivor count per frame (t = 0..T).  frames: optional list that receives the
+    tropical forward scores of every frame (fp32 [S], -inf = not a survivor), t = 0..T (lattice_search reads them).
     """
     S = g["num_states"]
     A = g["src"].size
@@ -274,6 +275,8 @@ def beam_search(g, lp, T, search_beam=np.inf):
     la[0] = 0
     bp = np.full((T, S), -1, dtype=np.int64)
     n_active = [1]
+    if frames is not None:
+        frames.append(alpha.copy())
     for t in range(T):
         x = arc_scores(g, lp[t])
         with np.errstate(invalid="ignore"):
@@ -292,6 +295,8 @@ def beam_search(g, lp, T, search_beam=np.inf):
         alpha = np.where(keep, m, np.float32(NEG_INF)).astype(np.float32)
         la = np.where(keep, ln, NEG_INF)
         n_active.append(int(keep.sum()))
+        if frames is not None:
+            frames.append(alpha.copy())
     fsrc, fid = g["src"][fin], ids[fin]
     vf = (alpha[fsrc] + g["score"][fin]).astype(np.float32)
     if vf.size == 0 or not np.isfinite(vf.max()):
@@ -308,6 +313,49 @@ def beam_search(g, lp, T, search_beam=np.inf):
     lf = la[fsrc] + g["score"][fin].astype(np.float64)
     tot_log = _seg_lse(lf, np.zeros(lf.size, dtype=np.int64), 1, np.float64)[0]
     return np.float32(score), path, float(tot_log), n_active
+
+
+def lattice_search(g, lp, T, search_beam=np.inf, output_beam=np.inf):
+    """beam_search followed by get_lattice's output_beam: the restatement wf_search_lattice is tested against.
+    [utils/lattice_analysis.py:125 `k2.get_lattice(..., search_beam=, output_beam=)` and :128 `get_tot_scores(True, True)`
+    of the lattice it returns; k2's own arithmetic is parity unpinned]
+
+    The lattice of the search: every arc from a survivor of frame t to a survivor of frame t + 1, and the final arcs
+    out of the survivors of frame T.  With alpha the tropical forward scores of the search and beta the tropical
+    backward scores within that lattice, an arc stays when fl32(alpha[src] + fl32(x + beta[dst])) >= best - output_beam
+    (x = fl32(w + lp); a final arc: fl32(alpha[src] + w)).  Returns (score, arcs, tot_log, lattice_arcs): best path as
+    beam_search, the log-semiring total (fp64) over the arcs that stay, and their number.
+    """
+    fr = []
+    score, path, _, _ = beam_search(g, lp, T, search_beam, frames=fr)
+    if not np.isfinite(score):
+        return score, path, NEG_INF, 0
+    S = g["num_states"]
+    em, fin = _split(g)
+    src, dst = g["src"][em], g["dst"][em]
+    thresh = np.float32(score - np.float32(output_beam)) if np.isfinite(output_beam) else np.float32(NEG_INF)
+    fsrc, fw = g["src"][fin], g["score"][fin].astype(np.float32)
+    aT = fr[T]
+    with np.errstate(invalid="ignore"):
+        live = np.isfinite(aT[fsrc]) & np.isfinite(fw)
+        bt = np.full(S, NEG_INF, dtype=np.float32)
+        np.maximum.at(bt, fsrc[live], fw[live])
+        kept = live & ((aT[fsrc] + fw).astype(np.float32) >= thresh)
+    narcs = int(kept.sum())
+    bl = _seg_lse(fw[kept].astype(np.float64), fsrc[kept], S, np.float64)
+    for t in range(T - 1, -1, -1):
+        x = arc_scores(g, lp[t])
+        a0, a1 = fr[t], fr[t + 1]
+        with np.errstate(invalid="ignore"):
+            vb = (x + bt[dst]).astype(np.float32)
+            live = np.isfinite(a0[src]) & np.isfinite(a1[dst]) & np.isfinite(vb)
+            kept = live & ((a0[src] + vb).astype(np.float32) >= thresh)
+            nbt = np.full(S, NEG_INF, dtype=np.float32)
+            np.maximum.at(nbt, src[live], vb[live])
+            nbl = _seg_lse(x[kept].astype(np.float64) + bl[dst[kept]], src[kept], S, np.float64)
+        narcs += int(kept.sum())
+        bt, bl = nbt, nbl
+    return score, path, float(bl[0]), narcs
 
 
 def graphloss(graphs, lp, segs, output_beam=None, reduction="sum", target_lengths=None,

@@ -227,3 +227,27 @@ def test_beam_search_restatement_is_viterbi_and_forward_at_infinite_beam():
         np.testing.assert_allclose(tl, o.forward(g, c["lp"][i], T)[1], rtol=1e-12)
         s2, p2, tl2, na2 = o.beam_search(g, c["lp"][i], T, 2.0)
         assert s2 <= s and tl2 <= tl + 1e-12 and all(a <= b for a, b in zip(na2, na))
+
+
+@pytest.mark.parametrize("topo,den", [("ctc", False), ("mmictc", True), ("3state-skip", True)])
+def test_lattice_search_restatement_against_prune_mask(topo, den):
+    """oracle.lattice_search (search + get_lattice's output_beam, what wf_search_lattice is tested against) against two
+    independent statements: with output_beam = inf it is beam_search; with search_beam = inf its total is the forward
+    sum over `prune_mask`'s arcs (the output_beam rule of intersect_dense, graph.py:61-62), and its arc count is that
+    mask's plus the final arcs that stay."""
+    from tests import util
+    c = util.random_case(52, topo, B=3, T=30, L=7, P=8, den=den)
+    for i, g in enumerate(c["ographs"]):
+        T, lp = int(c["segs"][i, 2]), c["lp"][i]
+        for sb in (np.inf, 4.0):
+            s, path, tl, na = o.lattice_search(g, lp, T, sb, np.inf)
+            s2, p2, tl2, _ = o.beam_search(g, lp, T, sb)
+            assert s == s2 and path == p2
+            np.testing.assert_allclose(tl, tl2, rtol=1e-12)
+        fin = g["label"] < 0
+        for ob in (2.0, 6.0):
+            s, path, tl, na = o.lattice_search(g, lp, T, np.inf, ob)
+            keep = o.prune_mask(g, lp, T, ob, dtype=np.float32)
+            np.testing.assert_allclose(tl, o.forward(g, lp, T, True, keep=keep)[1], rtol=1e-12)
+            assert 0 < na - int(keep.sum()) <= int(fin.sum())
+            assert tl <= o.lattice_search(g, lp, T, np.inf, np.inf)[2] + 1e-12

@@ -257,3 +257,81 @@ def test_max_active_with_more_tied_states_than_fit(tied):
         assert int(out["n_active"].max()) <= cap
     na = outs[0]["n_active"][0, 1:T + 1]
     assert int(na.min()) >= (cap if tied else cap // 2)      # (not tied: the refined bins cut within a bin of the cap)
+
+
+# ---------------------------------------------------------------------------------------------
+# output_beam of get_lattice (wf_search_lattice): the backward pass over the lattice the search left
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("output_beam", [1.5, 5.0, INF])
+@pytest.mark.parametrize("search_beam", [INF, 8.0])
+@pytest.mark.parametrize("topo,den", [("ctc", False), ("mmictc", True), ("3state-skip", True), ("2state_sil", False)])
+def test_output_beam_against_oracle(topo, den, search_beam, output_beam):
+    c, dense = _case(topo, den, seed=52)
+    out = wf.pruned_search(c["fsa"], dense, search_beam=search_beam, min_active_states=0, max_active_states=0,
+                           use_double_scores=True, output_beam=output_beam)
+    plain = wf.pruned_search(c["fsa"], dense, search_beam=search_beam, min_active_states=0, max_active_states=0,
+                             use_double_scores=True)
+    assert torch.equal(out["scores"], plain["scores"]) and torch.equal(out["arcs"], plain["arcs"])   # the best path stays
+    tot, narcs = out["tot_log"].cpu().numpy(), out["lattice_arcs"].cpu().numpy()
+    base = c["fsa"].fsa_arc_offsets
+    for i, g in enumerate(c["ographs"]):
+        T = int(c["segs"][i, 2])
+        s, path, tl, na = o.lattice_search(g, c["lp"][i], T, search_beam, output_beam)
+        gi = 0 if c["fsa"].utt2fsa is not None else i
+        assert out["scores"][i].item() == s
+        assert list(out["arcs"][i, :T + 1].cpu().numpy() - base[gi]) == path if path else True
+        assert narcs[i] == na
+        if np.isfinite(tl):
+            np.testing.assert_allclose(tot[i], tl, rtol=1e-9, atol=1e-9)
+        else:
+            assert tot[i] == -np.inf
+    if output_beam == INF:   # nothing on a complete path is dropped: the forward total, summed the other way round
+        np.testing.assert_allclose(tot, plain["tot_log"].cpu().numpy(), rtol=1e-6, atol=1e-5)
+    else:
+        assert np.all(tot <= plain["tot_log"].cpu().numpy() + 1e-9)
+        assert np.all(tot >= out["scores"].cpu().numpy().astype(np.float64) - 1e-4)   # the best path is in the lattice
+
+
+def test_output_beam_on_a_big_graph_with_active_state_limits():
+    g, lp, segs, fsa, dense = _big(40_000, B=4, T=40, seed=13)
+    pr = wf.pruned_search(fsa, dense, search_beam=7.0, min_active_states=0, max_active_states=0, use_double_scores=True,
+                          output_beam=3.0)
+    for i in range(4):
+        Ti = int(segs[i, 2])
+        s, path, tl, na = o.lattice_search(g, lp[i], Ti, 7.0, 3.0)
+        assert pr["scores"][i].item() == s
+        assert pr["lattice_arcs"][i].item() == na
+        if np.isfinite(tl):
+            np.testing.assert_allclose(pr["tot_log"][i].item(), tl, rtol=1e-9)
+        else:
+            assert pr["tot_log"][i].item() == -np.inf
+    # with max_active the survivors are the kernel's choice: the backward pass must still be consistent with the forward one
+    capped = wf.pruned_search(fsa, dense, search_beam=12.0, min_active_states=20, max_active_states=1500,
+                              use_double_scores=True)
+    same = wf.pruned_search(fsa, dense, search_beam=12.0, min_active_states=20, max_active_states=1500,
+                            use_double_scores=True, output_beam=INF)
+    assert torch.equal(capped["scores"], same["scores"]) and torch.equal(capped["arcs"], same["arcs"])
+    np.testing.assert_allclose(same["tot_log"].cpu().numpy(), capped["tot_log"].cpu().numpy(), rtol=1e-6)
+    tight = wf.pruned_search(fsa, dense, search_beam=12.0, min_active_states=20, max_active_states=1500,
+                             use_double_scores=True, output_beam=2.0)
+    assert torch.all(tight["tot_log"] <= same["tot_log"] + 1e-9)
+    assert torch.all(tight["lattice_arcs"] <= same["lattice_arcs"])
+    assert torch.all(tight["tot_log"] >= tight["scores"].double() - 1e-4)
+
+
+def test_get_lattice_applies_output_beam():
+    """lattice_analysis.py:125,128: the lattice total is over the lattice that output_beam leaves."""
+    g, lp, segs, fsa, dense = _big(12_001, B=2, T=30, seed=11)
+    one = wf.Fsa(fsa.arcs, fsa.aux_labels, fsa.fsa_arc_offsets, fsa.fsa_num_states)
+    x = torch.from_numpy(lp).to(DEV)
+    lens = torch.tensor([int(segs[0, 2]), int(segs[1, 2])])
+    narrow = decode.get_lattice(x, lens, one, search_beam=20.0, output_beam=2.0, min_active_states=0, max_active_states=0)
+    wide = decode.get_lattice(x, lens, one, search_beam=20.0, output_beam=INF, min_active_states=0, max_active_states=0)
+    tn, tw = narrow.get_tot_scores(True, True), wide.get_tot_scores(True, True)
+    assert torch.all(tn < tw)
+    for i in range(2):
+        Ti = int(segs[i, 2])
+        np.testing.assert_allclose(tn[i].item(), o.lattice_search(g, lp[i], Ti, 20.0, 2.0)[2], rtol=1e-9)
+        np.testing.assert_allclose(tw[i].item(), o.beam_search(g, lp[i], Ti, 20.0)[2], rtol=1e-6)
+    assert torch.equal(decode.one_best_decoding(narrow).scores, decode.one_best_decoding(wide).scores)

@@ -1,4 +1,5 @@
-"""Randomised parity run (GPU) of the beam-pruned search wf_search against oracle.beam_search: random graphs (skewed
+"""Randomised parity run (GPU) of the beam-pruned search wf_search against oracle.beam_search, and of wf_search_lattice
+(the search followed by get_lattice's output_beam) against oracle.lattice_search: random graphs (skewed
 out-degrees, states with thousands of arcs, fan-in hubs, dead ends), quantised weights and emissions (many exact ties:
 the lowest-arc-index rule and the `>= best - beam` boundary are hit all the time), random beams and lengths.
 usage: python tools/fuzz_search.py [cases] [seed] [max_states]   (test infrastructure: imports oracle/)"""
@@ -90,6 +91,23 @@ for case in range(n):
                 why.append(f"tot[{i}] {tot[i]} != {tl}")
         elif tot[i] != -np.inf:
             why.append(f"tot[{i}] {tot[i]} != -inf")
+    # get_lattice's output_beam over the same search (wf_search_lattice) against oracle.lattice_search
+    ob = float(rng.choice([0.5, 1.0, 2.5, 6.0, np.inf]))
+    lat = wf.pruned_search(fsa, dense, search_beam=beam, min_active_states=0, max_active_states=0,
+                           use_double_scores=True, output_beam=ob)
+    ltot, larcs = lat["tot_log"].cpu().numpy(), lat["lattice_arcs"].cpu().numpy()
+    if not (torch.equal(lat["scores"], out["scores"]) and torch.equal(lat["arcs"], out["arcs"])):
+        why.append("output_beam changed the best path")
+    for i, g in enumerate(gs):
+        Ti = int(segs[i, 2])
+        s, path, tl, na = o.lattice_search(g, lp[i], Ti, beam, ob)
+        if larcs[i] != na:
+            why.append(f"lattice_arcs[{i}] {larcs[i]} != {na} (output_beam {ob})")
+        if np.isfinite(tl):
+            if not np.isclose(ltot[i], tl, rtol=1e-9, atol=1e-9):
+                why.append(f"lattice tot[{i}] {ltot[i]} != {tl} (output_beam {ob})")
+        elif ltot[i] != -np.inf:
+            why.append(f"lattice tot[{i}] {ltot[i]} != -inf")
     # active-state limits: properties only (the oracle states the beam rule alone)
     cap = int(rng.integers(1, 300))
     lim = wf.pruned_search(fsa, dense, search_beam=beam, min_active_states=0, max_active_states=cap, return_active=True)

@@ -28,6 +28,7 @@ for peak in [float(x) for x in sys.argv[1:]] or [10.0, 6.0, 5.0, 4.0, 3.0]:
     for beam, mx in [(20.0, 10000), (12.0, 10000)]:
         ms, out = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, mx, log_tot=False, return_active=True))
         ms2, _ = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, mx, log_tot=True))
+        ms3, lat = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, mx, log_tot=True, output_beam=8.0))
         na = out["n_active"].float().mean().item()
-        print(f"peak {peak:4.1f} beam {beam:4.0f}: {ms:7.2f} ms (log total {ms2:7.2f}) exact {ms_exact:6.2f} ms  x{ms_exact / ms:5.2f}  "
+        print(f"peak {peak:4.1f} beam {beam:4.0f}: {ms:7.2f} ms (log total {ms2:7.2f}, + output_beam 8 {ms3:7.2f}, {lat['lattice_arcs'].double().mean().item() / T:7.0f} arcs/frame) exact {ms_exact:6.2f} ms  x{ms_exact / ms:5.2f}  "
               f"mean active {na:8.1f} max {out['n_active'].max().item():6d}  same path {bool(torch.equal(out['arcs'], exact['arcs']))}", flush=True)

@@ -4429,6 +4429,12 @@ struct SearchArgs {
     void* tot_log;
     int tot_double;
     int32_t* n_active;           // [B][Tmax+1] or null
+    // wf_search_lattice (the backward output_beam pass reads them), else null: (state, tropical score bits, first
+    // outgoing arc, out-degree) of every record of the arena, and per utterance the first record of every frame:
+    // ftab[t] .. ftab[t + 1] are frame t's
+    int4* rinfo;
+    int64_t* ftab;               // [B][ftab_stride]
+    int ftab_stride;
     int prof;                    // measurement aid (WF_SEARCH_PROFILE=1): workgroup 0 prints the cycles of its phases
     // search_mw_kernel: `wgs` workgroups per utterance
     int wgs, B, solo_max;
@@ -4451,6 +4457,10 @@ struct SearchCtl {
     int pad;
     struct Gen { int ncand; unsigned fmax; int nsurv1, nsurv2; unsigned smin, G1, G2; int pad; } c[3];
     int hist[1024];
+    // search_back_kernel (several workgroups per utterance): its barrier counter, its abort flag, the lattice's arc count
+    unsigned bbar;
+    int babort;
+    unsigned long long narcs;
 };
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -4508,6 +4518,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
     int2* arena = p.arena + R[WF_SR_AOFF];
     int32_t* out = p.best_arcs + (int64_t)u * (p.Tmax + 1);
     int32_t* nact = p.n_active ? p.n_active + (int64_t)u * (p.Tmax + 1) : nullptr;
+    int4* rinfo = p.rinfo ? p.rinfo + R[WF_SR_AOFF] : nullptr;
+    int64_t* ftab = p.ftab ? p.ftab + (int64_t)u * p.ftab_stride : nullptr;
     for (int i = tid; i <= p.Tmax; i += kSearchThreads) { out[i] = -1; if (nact) nact[i] = 0; }
     const float* lp0 = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
     const float ninf = -INFINITY;
@@ -4518,6 +4530,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
         xarcs[0] = make_int2(off[0], off[1] - off[0]);
         s_xa0[0] = off[0]; s_xv[0] = 0.f; s_pfx[0] = off[1] - off[0];   // (s_pfx holds the DEGREES until the scan)
         arena[0] = make_int2(-1, -1);
+        if (rinfo) { rinfo[0] = make_int4(0, __float_as_int(0.f), off[0], off[1] - off[0]); ftab[0] = 0; ftab[1] = 1; }
         slot[0] = 0;
         if (nact) nact[0] = 1;
         s_G = f2ord(0.f);
@@ -4707,6 +4720,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
                         if (isbest || k < lim) {
                             const float sc = ord2f((uint32_t)(pk[j] >> 32));
                             arena[base + k] = make_int2((int)(0xffffffffu - (uint32_t)pk[j]), (int)(base_prev + ow[j]));
+                            if (rinfo) rinfo[base + k] = make_int4(s[j], __float_as_int(sc), o0[j], o1[j] - o0[j]);
                             slot[s[j]] = (int)(base + k);
                             xstate[k] = s[j];
                             xscore[k] = sc;
@@ -4789,6 +4803,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
         if (tid == 0 && nact) nact[t + 1] = nX;
         base_prev = base;
         base += nX;
+        if (tid == 0 && ftab) ftab[t + 2] = base;
         __syncthreads();
         SR_MARK(4);
     }
@@ -4920,6 +4935,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
     int2* arena = p.arena + R[WF_SR_AOFF];
     int32_t* out = p.best_arcs + (int64_t)u * (p.Tmax + 1);
     int32_t* nact = p.n_active ? p.n_active + (int64_t)u * (p.Tmax + 1) : nullptr;
+    int4* rinfo = p.rinfo ? p.rinfo + R[WF_SR_AOFF] : nullptr;
+    int64_t* ftab = p.ftab ? p.ftab + (int64_t)u * p.ftab_stride : nullptr;
     SearchCtl* ctl = p.ctl + u;
     const float* lp0 = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
     const float ninf = -INFINITY;
@@ -4954,10 +4971,14 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
             xstate[0] = 0; xscore[0] = 0.f; xla[0] = 0.0;
             xarcs[0] = make_int2(off[0], off[1] - off[0]);
             arena[0] = make_int2(-1, -1);
+            if (rinfo) { rinfo[0] = make_int4(0, __float_as_int(0.f), off[0], off[1] - off[0]); ftab[0] = 0; ftab[1] = 1; }
             slot[0] = 0;
             if (nact) nact[0] = 1;
         }
     }
+    unsigned long long mc[6] = {0, 0, 0, 0, 0, 0}, mt0 = 0;
+    long long mfr[2] = {0, 0};
+#define MW_MARK(i) do { if (p.prof) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); mc[i] += now_ - mt0; mt0 = now_; } } while (0)
     int nX = 1;
     int64_t base = 1, base_prev = 0;
     bool dead = false;
@@ -4993,6 +5014,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
             continue;
         }
         SearchCtl::Gen* C = solo ? &s_gen : &ctl->c[t % 3];
+        if (p.prof) { mt0 = __builtin_amdgcn_s_memtime(); ++mfr[solo ? 0 : 1]; }
         if (g == 0 && tid == 0) {
             SearchCtl::Gen* Cn = &ctl->c[(t + 1) % 3];   // (last used two frames ago; the next frame's counters)
             Cn->ncand = 0; Cn->fmax = 0; Cn->nsurv1 = 0; Cn->nsurv2 = 0; Cn->smin = 0xffffffffu; Cn->G1 = 0; Cn->G2 = 0;
@@ -5079,7 +5101,9 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
                     if (s_ncand) atomicAdd(&C->ncand, s_ncand);
                 }
             }
+            if (!solo) MW_MARK(0);
             if (sync_all()) return;   // every value of the pass is final, for every workgroup
+            if (!solo) MW_MARK(1);
         }
         // ---------------- prune
         const int n = s_ncand;                     // this workgroup's candidates
@@ -5119,6 +5143,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
                         const int k = wb + __popcll(mk & ((1ull << lane) - 1ull));
                         if (k < cap) {
                             arena[base + k] = make_int2((int)(0xffffffffu - (uint32_t)pk), (int)(base_prev + ow));
+                            if (rinfo) rinfo[base + k] = make_int4(s, __float_as_int(sc), o0, o1 - o0);
                             slot[s] = (int)(base + k);
                             xstate[k] = s;
                             xscore[k] = sc;
@@ -5140,7 +5165,9 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
             compact(true);
             for (int o = 32; o > 0; o >>= 1) lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, o, 64));
             if (lane == 0 && lmin != 0xffffffffu) atomicMin(&C->smin, lmin);
+            if (!solo) MW_MARK(2);
             if (sync_all()) return;
+            if (!solo) MW_MARK(3);
             const int cnt = ld_fresh(&C->nsurv1);
             const bool tighten = cnt > cap, loosen = !tighten && cnt < want_min;
             if (tighten || loosen) {   // (uniform over the utterance's workgroups)
@@ -5193,10 +5220,12 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
             if (lsum && nX > 0) G = ord2f(ld_fresh(second ? &C->G2 : &C->G1));
         }
         __syncthreads();   // (s_gen / s_ncand are rewritten by the next frame)
+        MW_MARK(solo ? 5 : 4);
         lds_valid = solo && nX <= kSearchXL;
         if (g == 0 && tid == 0 && nact) nact[t + 1] = nX;
         base_prev = base;
         base += nX;
+        if (g == 0 && tid == 0 && ftab) ftab[t + 2] = base;
         ++t;
         if (nX == 0) dead = true;
         if (solo && NW > 1) {
@@ -5215,6 +5244,9 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
         }
         if (dead) break;
     }
+    if (p.prof && u == 0 && tid == 0 && (g == 0 || g == NW - 1))
+        printf("search_mw_kernel utterance 0 workgroup %d of %d: %lld solo + %lld shared frames | cycles in shared frames: expand %llu, wait %llu, compact %llu, wait %llu, second compaction + tail %llu | solo frames %llu\n",
+               g, NW, mfr[0], mfr[1], mc[0], mc[1], mc[2], mc[3], mc[4], mc[5]);
     if (g != 0) return;
     // ---------------- final arcs over the survivors of frame T (workgroup 0)
     const int NF = I[WF_I_NF];
@@ -5280,6 +5312,241 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
             else ((float*)p.tot_log)[u] = (float)totl;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// search_back_kernel: the output_beam of k2.get_lattice (utils/lattice_analysis.py:125) over the lattice the forward
+// search left behind.  The lattice is every arc between a survivor of frame t and a survivor of frame t + 1 (and the
+// final arcs out of the survivors of frame T); the forward kernels recorded, per record of the arena, the state and
+// its tropical forward score (rinfo) and where each frame's records begin (ftab).  One workgroup per utterance walks
+// the frames backwards, one lane per record: the tropical backward score bt is the max over the record's arcs of
+// (w + e) + bt[dst]; an arc stays in the output lattice when alpha + ((w + e) + bt[dst]) >= best - output_beam (fp32,
+// this association); bl, the log-semiring backward score over the arcs that stay (fp64), ends as the pruned lattice's
+// total at the start state's record.  A state's record of frame t + 1 is found through slot[] (free after the forward
+// pass), rewritten frame by frame and validated against the frame's range and the record's state.
+// ------------------------------------------------------------------------------------------
+struct SearchBackArgs {
+    const int32_t* blob;
+    const int64_t* utt;
+    const int64_t* tab;
+    const float* lp;
+    int64_t strideB, strideT;
+    int32_t* slot;               // state -> record, frames of the parity of T
+    int32_t* slot2;              // the other frames (the forward pass's candidate list, free by now)
+    const int4* rinfo;
+    float* bt;                   // [records]
+    double* bl;                  // [records]
+    const int64_t* ftab;
+    int ftab_stride;
+    const float* best_score;
+    float output_beam;
+    void* tot_log;
+    int tot_double;
+    long long* lattice_arcs;     // [B] or null: arcs of the output lattice (final arcs included)
+    int wgs, B, solo_max;        // workgroups per utterance (workgroup b serves utterance b % B, as search_mw_kernel)
+    SearchCtl* ctl;              // [B] (wgs > 1, or redo)
+    int redo;                    // second launch, one workgroup per utterance: only the utterances whose babort is set
+};
+
+constexpr int kBackRecs = 2;     // records per lane in flight (the frame is a chain of dependent loads: overlap two)
+constexpr int kBackArcs = 4;     // arcs of a record in flight
+
+__global__ void __launch_bounds__(kSearchThreads) search_back_kernel(SearchBackArgs p) {
+    __shared__ unsigned long long s_arcs;
+    __shared__ int s_abort;
+    const int u = blockIdx.x % p.B, g = blockIdx.x / p.B, tid = threadIdx.x;
+    SearchCtl* ctl = p.ctl ? p.ctl + u : nullptr;
+    if (p.redo && !ctl->babort) return;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int64_t* R = p.tab + (int64_t)u * WF_SR_WORDS;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int T = (int)U[WF_U_T];
+    const float ninf = -INFINITY;
+    const float best = p.best_score[u];
+    auto put = [&](double tot, long long arcs) {
+        if (p.tot_double) ((double*)p.tot_log)[u] = tot; else ((float*)p.tot_log)[u] = (float)tot;
+        if (p.lattice_arcs) p.lattice_arcs[u] = arcs;
+    };
+    if (!(best > ninf)) {   // no path survived the forward search
+        if (tid == 0 && g == 0) put(-INFINITY, 0);
+        return;
+    }
+    const int64_t* ftab = p.ftab + (int64_t)u * p.ftab_stride;
+    // Several workgroups share the frames of an utterance whose lattice is wide (one workgroup's scattered loads are what
+    // bounds a frame: ~5 cache lines per arc); a narrow one is walked by workgroup 0 alone, without barriers in device
+    // memory.  (Every workgroup of the utterance reads the same record count: the decision is uniform.)
+    const bool multi = p.wgs > 1 && ftab[T + 1] >= (int64_t)max(p.solo_max, 2) * (T + 1);   // (records per frame, on average)
+    if (!multi && g != 0) return;
+    const int NW = multi ? p.wgs : 1;
+    unsigned nbar = 0;
+    // barrier of the utterance's workgroups, bounded as search_mw_kernel's: true = given up (everyone leaves; the second
+    // launch walks the utterance with one workgroup)
+    auto sync_all = [&]() -> bool {
+        __syncthreads();
+        if (!multi) return false;
+        if (tid == 0) {
+            ++nbar;
+            const unsigned target = nbar * (unsigned)NW;
+            __threadfence();
+            atomicAdd(&ctl->bbar, 1u);
+            long spins = 0;
+            bool ab = false;
+            while (ld_fresh(&ctl->bbar) < target) {
+                if (++spins > 64) __builtin_amdgcn_s_sleep(2);
+                if ((spins & 255) == 0 && (ld_fresh(&ctl->babort) || spins > kSearchSpinLimit)) { ab = true; break; }
+            }
+            if (ab) atomicExch(&ctl->babort, 1);
+            __threadfence();
+            s_abort = ab || ld_fresh(&ctl->babort);
+        }
+        __syncthreads();
+        return s_abort != 0;
+    };
+    if (p.redo && tid == 0) ctl->narcs = 0ull;
+    const float thresh = best - p.output_beam;   // (-inf with output_beam = inf: every arc on a complete path stays)
+    const int direct = I[WF_I_DIRECT];
+    const int4* orec = (const int4*)(p.blob + I[WF_I_OUT_REC]);
+    const int32_t* labels = p.blob + I[WF_I_LABELS];
+    // slot_of(t): state -> record of frame t.  Two arrays by the frame's parity: frame t's map is written while frame
+    // t + 1's is being read.  What other frames (or the forward pass) left in them is told apart by the frame's range of
+    // records and the record's state.
+    int32_t* slot_a = p.slot + R[WF_SR_SOFF];
+    int32_t* slot_b = p.slot2 + R[WF_SR_SOFF];
+    auto slot_of = [&](int t) -> int32_t* { return ((T - t) & 1) ? slot_b : slot_a; };
+    const int4* rinfo = p.rinfo + R[WF_SR_AOFF];
+    float* bt = p.bt + R[WF_SR_AOFF];
+    double* bl = p.bl + R[WF_SR_AOFF];
+    uint32_t* btu = (uint32_t*)bt;   // frame T: order-preserving bits under atomicMax, 0 = no final arc
+    const float* lp0 = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
+    if (tid == 0) s_arcs = 0ull;
+    long long narcs = 0;
+
+    // ---------------- frame T: the final arcs (workgroup 0)
+    if (g == 0) {
+        const int64_t b1 = ftab[T];
+        const int n1 = (int)(ftab[T + 1] - b1);
+        const int NF = I[WF_I_NF];
+        const int32_t* fsrc = p.blob + I[WF_I_FIN_SRC];
+        const float* fw = (const float*)(p.blob + I[WF_I_FIN_W]);
+        int32_t* slot = slot_of(T);
+        for (int i = tid; i < n1; i += kSearchThreads) { slot[rinfo[b1 + i].x] = (int)(b1 + i); btu[b1 + i] = 0u; bl[b1 + i] = 0.0; }
+        __syncthreads();
+        auto record = [&](int s) -> int64_t {
+            const int64_t j = ld_fresh(slot + s);
+            return (j >= b1 && j < b1 + n1 && rinfo[j].x == s) ? j : -1;
+        };
+        for (int i = tid; i < NF; i += kSearchThreads) {
+            const int64_t j = record(fsrc[i]);
+            if (j >= 0 && fw[i] > ninf) atomicMax(&btu[j], f2ord(fw[i]));
+        }
+        __syncthreads();
+        for (int i = tid; i < NF; i += kSearchThreads) {
+            const int64_t j = record(fsrc[i]);
+            if (j < 0 || !(fw[i] > ninf)) continue;
+            if (__int_as_float(rinfo[j].y) + fw[i] >= thresh) {
+                atomicAdd(&bl[j], exp((double)fw[i] - (double)ord2f(ld_fresh(btu + j))));
+                ++narcs;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n1; i += kSearchThreads) {
+            const uint32_t o = ld_fresh(btu + b1 + i);
+            const double acc = ld_fresh(bl + b1 + i);
+            const float m = o ? ord2f(o) : ninf;
+            bt[b1 + i] = m;
+            bl[b1 + i] = acc > 0.0 ? (double)m + log(acc) : -INFINITY;
+        }
+    }
+    if (sync_all()) return;
+    // ---------------- frames T - 1 .. 0 (a contiguous block of the frame's records per workgroup)
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t b0 = ftab[t], b1 = ftab[t + 1];
+        const int n0 = (int)(b1 - b0), n1 = (int)(ftab[t + 2] - b1);
+        const float* erow = lp0 + (int64_t)t * p.strideT;
+        const int32_t* slot1 = slot_of(t + 1);
+        int32_t* slot0 = slot_of(t);
+        const bool shared = NW > 1 && n0 >= 4 * NW;
+        const int x0 = shared ? (int)((long long)n0 * g / NW) : 0, x1 = shared ? (int)((long long)n0 * (g + 1) / NW) : (g == 0 ? n0 : 0);
+        for (int i0 = x0; i0 < x1; i0 += kBackRecs * kSearchThreads) {
+            int4 me[kBackRecs];
+            float m[kBackRecs];
+            double mx[kBackRecs], acc[kBackRecs];
+            int maxdeg = 0;
+#pragma unroll
+            for (int r = 0; r < kBackRecs; ++r) {
+                const int i = i0 + r * kSearchThreads + tid;
+                me[r] = i < x1 ? rinfo[b0 + i] : make_int4(0, 0, 0, 0);
+                if (i < x1) slot0[me[r].x] = (int)(b0 + i);
+                m[r] = ninf; mx[r] = -INFINITY; acc[r] = 0.0;
+                maxdeg = max(maxdeg, me[r].w);
+            }
+            for (int q0 = 0; q0 < maxdeg; q0 += kBackArcs) {
+                int d[kBackRecs][kBackArcs];
+                float we[kBackRecs][kBackArcs], tb[kBackRecs][kBackArcs];
+                int64_t j[kBackRecs][kBackArcs];
+                double lb[kBackRecs][kBackArcs];
+                int st[kBackRecs][kBackArcs];
+#pragma unroll
+                for (int r = 0; r < kBackRecs; ++r)
+#pragma unroll
+                    for (int k = 0; k < kBackArcs; ++k) {
+                        const bool in = q0 + k < me[r].w;
+                        const int4 rec = orec[me[r].z + (in ? q0 + k : 0)];
+                        d[r][k] = in ? rec.x : -1;
+                        we[r][k] = __int_as_float(rec.z) + erow[direct ? rec.y : labels[rec.y]];
+                    }
+#pragma unroll
+                for (int r = 0; r < kBackRecs; ++r)
+#pragma unroll
+                    for (int k = 0; k < kBackArcs; ++k) {
+                        const int64_t x = d[r][k] >= 0 ? (int64_t)ld_fresh(slot1 + d[r][k]) : -1;
+                        j[r][k] = (x >= b1 && x < b1 + n1) ? x : -1;
+                    }
+#pragma unroll
+                for (int r = 0; r < kBackRecs; ++r)
+#pragma unroll
+                    for (int k = 0; k < kBackArcs; ++k) {
+                        const int64_t x = j[r][k] >= 0 ? j[r][k] : b1;   // (b1: a record that exists; its values are not used)
+                        st[r][k] = rinfo[x].x;
+                        tb[r][k] = ld_fresh(bt + x);
+                        lb[r][k] = ld_fresh(bl + x);
+                    }
+#pragma unroll
+                for (int r = 0; r < kBackRecs; ++r)
+#pragma unroll
+                    for (int k = 0; k < kBackArcs; ++k) {
+                        if (j[r][k] < 0 || st[r][k] != d[r][k]) continue;
+                        const float vb = we[r][k] + tb[r][k];
+                        if (!(vb > ninf)) continue;
+                        m[r] = max(m[r], vb);
+                        if (__int_as_float(me[r].y) + vb >= thresh) {
+                            ++narcs;
+                            const double v = (double)we[r][k] + lb[r][k];
+                            if (v > mx[r]) { acc[r] = acc[r] * exp(mx[r] - v) + 1.0; mx[r] = v; }
+                            else if (v > -INFINITY) acc[r] += exp(v - mx[r]);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < kBackRecs; ++r) {
+                const int i = i0 + r * kSearchThreads + tid;
+                if (i < x1) {
+                    bt[b0 + i] = m[r];
+                    bl[b0 + i] = acc[r] > 0.0 ? mx[r] + log(acc[r]) : -INFINITY;
+                }
+            }
+        }
+        if (sync_all()) return;   // (frame t's scores and map are complete; every lookup of frame t + 1 is over)
+    }
+    if (narcs) atomicAdd(&s_arcs, (unsigned long long)narcs);
+    __syncthreads();
+    if (!ctl) {
+        if (tid == 0) put(ld_fresh(bl + 0), (long long)s_arcs);
+        return;
+    }
+    if (tid == 0 && s_arcs) atomicAdd(&ctl->narcs, s_arcs);
+    if (sync_all()) return;
+    if (tid == 0 && g == 0) put(ld_fresh(bl + 0), (long long)ld_fresh(&ctl->narcs));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -7163,9 +7430,10 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
 namespace {
 struct SearchPlan {
     Plan P;   // only P.utt (utterance table followed by the search table) and P.off_utt are used
-    size_t off_best = 0, off_lsum = 0, off_slot = 0, off_cand = 0, off_cpk = 0, off_cls = 0, off_arcown = 0, off_xs = 0, off_xv = 0, off_xl = 0, off_xa = 0, off_arena = 0, off_ctl = 0, total = 0;
+    size_t off_best = 0, off_lsum = 0, off_slot = 0, off_cand = 0, off_cpk = 0, off_cls = 0, off_arcown = 0, off_xs = 0, off_xv = 0, off_xl = 0, off_xa = 0, off_arena = 0, off_ctl = 0, off_rinfo = 0, off_bt = 0, off_bl = 0, off_ftab = 0, total = 0;
     int64_t nstates = 0;
     int wgs = 1;
+    int ftab_stride = 0;   // (lattice: longest segment + 2)
 };
 // Workgroups per utterance (search_mw_kernel when > 1): up to 8 while the launch fills at most half of the chip, and only
 // where the active set may grow past what one workgroup handles well.  WF_SEARCH_WGS forces a number (1: search_kernel).
@@ -7184,7 +7452,7 @@ int search_wgs(int B, int max_active) {
     return g;
 }
 int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V, int max_active,
-                bool logsum, SearchPlan* S) {
+                bool logsum, bool lattice, SearchPlan* S) {
     int rc = check_blob(graph_host);
     if (rc) return rc;
     if (B < 1 || !seg || V < 1) return wf_fail(WF_EINVAL, "bad B/seg/V");
@@ -7212,6 +7480,7 @@ int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* s
         na += (int64_t)I[WF_I_A] + I[WF_I_NF];
         nx += cap;
         nr += (int64_t)(T + 1) * cap + 1;
+        S->ftab_stride = std::max(S->ftab_stride, T + 2);
     }
     S->nstates = ns;
     const size_t W = (size_t)(S->wgs = search_wgs(B, max_active));   // (every workgroup of an utterance lists its own candidates)
@@ -7230,6 +7499,12 @@ int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* s
     S->off_xl = o; o = align_up(o + 8 * (size_t)nx, 256);
     S->off_xa = o; o = align_up(o + 8 * (size_t)nx, 256);
     S->off_arena = o; o = align_up(o + 8 * (size_t)nr, 256);
+    if (lattice) {   // the backward output_beam pass: per record (state, score), tropical / log backward scores; frame table
+        S->off_rinfo = o; o = align_up(o + 16 * (size_t)nr, 256);
+        S->off_bt = o; o = align_up(o + 4 * (size_t)nr, 256);
+        S->off_bl = o; o = align_up(o + 8 * (size_t)nr, 256);
+        S->off_ftab = o; o = align_up(o + 8 * (size_t)B * S->ftab_stride, 256);
+    }
     S->total = o;
     return WF_OK;
 }
@@ -7239,17 +7514,28 @@ extern "C" int wf_search_workspace_bytes(const void* graph_host, const int32_t* 
                                          int32_t V, int32_t max_active_states, int32_t want_log_tot, size_t* bytes) {
     if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
     SearchPlan S;
-    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, want_log_tot != 0, &S);
+    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, want_log_tot != 0, false, &S);
     if (rc) return rc;
     *bytes = S.total + 256;
     return WF_OK;
 }
 
-extern "C" int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
-                         int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
-                         float search_beam, int32_t min_active_states, int32_t max_active_states, uint32_t flags,
-                         float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+extern "C" int wf_search_lattice_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B,
+                                                 int32_t V, int32_t max_active_states, size_t* bytes) {
+    if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
+    SearchPlan S;
+    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, true, true, &S);
+    if (rc) return rc;
+    *bytes = S.total + 256;
+    return WF_OK;
+}
+
+namespace {
+int search_impl(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
+                int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
+                float search_beam, int32_t min_active_states, int32_t max_active_states, uint32_t flags,
+                float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
+                size_t workspace_bytes, void* stream, bool lattice, float output_beam, int64_t* lattice_arcs) {
     if (!graph_dev || !log_probs || !best_score || !best_arcs || !workspace || !seg) return wf_fail(WF_EINVAL, "wf_search: null pointer");
     if (!(search_beam > 0.f)) return wf_fail(WF_EINVAL, "wf_search: search_beam must be > 0 (inf: no beam)");
     if (min_active_states < 0) return wf_fail(WF_EINVAL, "wf_search: min_active_states < 0");
@@ -7257,7 +7543,7 @@ extern "C" int wf_search(const void* graph_host, const void* graph_dev, const in
     int rc = check_segments("wf_search", seg, B, num_seqs, Tmax);
     if (rc) return rc;
     SearchPlan S;
-    rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, tot_log != nullptr, &S);
+    rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, tot_log != nullptr, lattice, &S);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + S.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, S.total + 256);
@@ -7287,6 +7573,11 @@ extern "C" int wf_search(const void* graph_host, const void* graph_dev, const in
     a.best_score = best_score; a.best_arcs = best_arcs; a.Tmax = Tmax;
     a.tot_log = tot_log; a.tot_double = (flags & WF_DOUBLE_ACC) ? 1 : 0;
     a.n_active = n_active;
+    if (lattice) {
+        a.rinfo = (int4*)(ws + S.off_rinfo);
+        a.ftab = (int64_t*)(ws + S.off_ftab);
+        a.ftab_stride = S.ftab_stride;
+    }
     static const int search_prof = getenv("WF_SEARCH_PROFILE") ? atoi(getenv("WF_SEARCH_PROFILE")) : 0;
     a.prof = search_prof;
     if (S.wgs > 1) {
@@ -7300,6 +7591,49 @@ extern "C" int wf_search(const void* graph_host, const void* graph_dev, const in
         a.redo_stride = (int)(sizeof(SearchCtl) / sizeof(int32_t));
     }
     hipLaunchKernelGGL(search_kernel, dim3(B), dim3(kSearchThreads), 0, st, a);
+    if (lattice) {   // the forward total is replaced by the total of the lattice that output_beam leaves
+        SearchBackArgs b{};
+        b.blob = a.blob; b.utt = a.utt; b.tab = a.tab;
+        b.lp = log_probs; b.strideB = strideB; b.strideT = strideT;
+        b.slot = a.slot; b.slot2 = a.cand; b.rinfo = a.rinfo;
+        b.bt = (float*)(ws + S.off_bt);
+        b.bl = (double*)(ws + S.off_bl);
+        b.ftab = a.ftab; b.ftab_stride = a.ftab_stride;
+        b.best_score = best_score;
+        b.output_beam = output_beam;
+        b.tot_log = tot_log; b.tot_double = a.tot_double;
+        b.lattice_arcs = (long long*)lattice_arcs;
+        b.wgs = 1; b.B = B;
+        if (S.wgs > 1) {   // (the control blocks were zeroed before the forward launch)
+            b.wgs = S.wgs; b.ctl = a.ctl; b.solo_max = a.solo_max;
+            hipLaunchKernelGGL(search_back_kernel, dim3(B * S.wgs), dim3(kSearchThreads), 0, st, b);
+            b.wgs = 1; b.redo = 1;   // what the barrier gave up on: one workgroup, from the start
+        }
+        hipLaunchKernelGGL(search_back_kernel, dim3(B), dim3(kSearchThreads), 0, st, b);
+    }
     HIP_TRY(hipGetLastError());
     return WF_OK;
+}
+}  // namespace
+
+extern "C" int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
+                         int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
+                         float search_beam, int32_t min_active_states, int32_t max_active_states, uint32_t flags,
+                         float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    return search_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, V, seg, B, Tmax, search_beam,
+                       min_active_states, max_active_states, flags, best_score, best_arcs, tot_log, n_active, workspace,
+                       workspace_bytes, stream, false, 0.f, nullptr);
+}
+
+extern "C" int wf_search_lattice(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
+                                 int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B,
+                                 int32_t Tmax, float search_beam, float output_beam, int32_t min_active_states,
+                                 int32_t max_active_states, uint32_t flags, float* best_score, int32_t* best_arcs, void* tot_log,
+                                 int64_t* lattice_arcs, int32_t* n_active, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!tot_log) return wf_fail(WF_EINVAL, "wf_search_lattice: null tot_log");
+    if (!(output_beam > 0.f)) return wf_fail(WF_EINVAL, "wf_search_lattice: output_beam must be > 0 (inf: no pruning)");
+    return search_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, V, seg, B, Tmax, search_beam,
+                       min_active_states, max_active_states, flags, best_score, best_arcs, tot_log, n_active, workspace,
+                       workspace_bytes, stream, true, output_beam, lattice_arcs);
 }

@@ -13,13 +13,16 @@ materialised:
 * ``get_lattice`` -> the beam-pruned frame-synchronous search ``wf_search`` (graph.pruned_search): token passing with
   ``search_beam`` and ``min/max_active_states`` over decoding graphs of any size; it yields the best path, the tropical
   score and the log-semiring total of the pruned lattice in one pass.  ``search_beam=inf, max_active_states=0`` is the
-  exact search.  ``output_beam`` of get_lattice (k2: a backward pass that drops lattice arcs further than output_beam
-  from the best path) is accepted and NOT applied: the log-semiring total is over every path through the states that
-  survived ``search_beam``, a superset of k2's output lattice (the best path and the tropical score do not depend on it).
+  exact search.  ``output_beam`` of get_lattice is applied as k2 applies it, backwards over the finished lattice
+  (wf_search_lattice: one more launch keeps the arcs with alpha + score + beta within output_beam of the best path):
+  ``get_tot_scores(True, True)`` is the total of that smaller lattice; the best path and the tropical score do not
+  depend on it.  ``output_beam=None`` or inf skips the backward launch (total over everything search_beam kept).
   k2's own beam arithmetic is parity unpinned (the reference holds no fixture), see INTEGRATION.md.
 * ``intersect_dense(graphs, dense, output_beam)`` -> the exact sweeps (wf_tot_scores / wf_viterbi) over the whole
   product, as in training (graph.py:61-62).
 """
+import math
+
 import torch
 
 from .fsa import DenseFsaVec, Fsa, create_fsa_vec
@@ -92,8 +95,9 @@ def get_lattice(log_prob, log_prob_len, decoding_graph, search_beam=20, output_b
                 max_active_states=10000, subsampling_factor=1):
     """k2.get_lattice (icefall-style signature; lattice_analysis.py:125).  log_prob: [B, T, V] on the GPU.
     The search itself runs at the first query (get_tot_scores / one_best_decoding)."""
-    # (output_beam: k2 prunes the finished lattice backwards with it; the forward search here keeps search_beam alone)
     search = dict(search_beam=float(search_beam), min_active_states=int(min_active_states), max_active_states=int(max_active_states))
+    if output_beam is not None and math.isfinite(float(output_beam)):
+        search["output_beam"] = float(output_beam)   # (the backward pass over the finished lattice)
     return DenseLattice(_as_vec(decoding_graph, log_prob.shape[0]), _dense_from(log_prob, log_prob_len), search)
 
 

@@ -506,36 +506,57 @@ def _path_labels(graph, arcs):
 
 def pruned_search(graph: Fsa, dense: DenseFsaVec, search_beam: float = 20.0, min_active_states: int = 30,
                   max_active_states: int = 10000, log_tot: bool = True, use_double_scores: bool = False,
-                  return_active: bool = False):
+                  return_active: bool = False, output_beam=None):
     """Beam-pruned frame-synchronous search (k2.get_lattice's search, utils/lattice_analysis.py:125; wf_search).
 
     Returns dict(scores, arcs, labels, aux_labels) like best_path, plus ``tot_log`` (log-semiring total of the pruned
     lattice; fp64 with use_double_scores) when log_tot, and ``n_active`` int32 [B, T+1] when return_active.
     search_beam = inf and max_active_states = 0 give the exact search.
+
+    ``output_beam`` (get_lattice's, a float; None: not applied): after the search, one backward launch over the lattice it
+    left keeps the arcs within output_beam of the best path (wf_search_lattice); ``tot_log`` is then the total of that
+    smaller lattice and ``lattice_arcs`` (int64 [B]) its number of arcs.  The best path does not depend on it.
     """
     lp, seg, B = _check_inputs(graph, dense)
     lib = _lib.lib()
     dev = lp.device
     N, T, V = lp.shape
     flags = _lib.WF_DOUBLE_ACC if use_double_scores else 0
+    lattice = output_beam is not None
+    if lattice and not log_tot:
+        raise ValueError("pruned_search: output_beam only changes tot_log; pass log_tot=True")
     n = C.c_size_t(0)
-    _lib.check(lib.wf_search_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V,
-                                              int(max_active_states), int(bool(log_tot)), C.byref(n)))
+    if lattice:
+        _lib.check(lib.wf_search_lattice_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V,
+                                                          int(max_active_states), C.byref(n)))
+    else:
+        _lib.check(lib.wf_search_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V,
+                                                  int(max_active_states), int(bool(log_tot)), C.byref(n)))
     ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
     scores = torch.empty(B, dtype=torch.float32, device=dev)
     arcs = torch.empty((B, T + 1), dtype=torch.int32, device=dev)
     tot = torch.empty(B, dtype=torch.float64 if use_double_scores else torch.float32, device=dev) if log_tot else None
     nact = torch.empty((B, T + 1), dtype=torch.int32, device=dev) if return_active else None
+    narcs = torch.empty(B, dtype=torch.int64, device=dev) if lattice else None
     with _on(dev):
-        _lib.check(lib.wf_search(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
-                                 _ptr(lp), lp.stride(0), lp.stride(1), N, V, _np_ptr(seg), B, T, float(search_beam),
-                                 int(min_active_states), int(max_active_states), flags, _ptr(scores), _ptr(arcs),
-                                 _ptr(tot), _ptr(nact), _ptr(ws), n.value, _stream(dev)))
+        if lattice:
+            _lib.check(lib.wf_search_lattice(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
+                                             _ptr(lp), lp.stride(0), lp.stride(1), N, V, _np_ptr(seg), B, T,
+                                             float(search_beam), float(output_beam), int(min_active_states),
+                                             int(max_active_states), flags, _ptr(scores), _ptr(arcs), _ptr(tot),
+                                             _ptr(narcs), _ptr(nact), _ptr(ws), n.value, _stream(dev)))
+        else:
+            _lib.check(lib.wf_search(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
+                                     _ptr(lp), lp.stride(0), lp.stride(1), N, V, _np_ptr(seg), B, T, float(search_beam),
+                                     int(min_active_states), int(max_active_states), flags, _ptr(scores), _ptr(arcs),
+                                     _ptr(tot), _ptr(nact), _ptr(ws), n.value, _stream(dev)))
     res = {"scores": scores, "arcs": arcs}
     res["labels"], res["aux_labels"] = _path_labels(graph, arcs)
     if log_tot:
         res["tot_log"] = tot
     if return_active:
         res["n_active"] = nact
+    if lattice:
+        res["lattice_arcs"] = narcs
     return res
 
