@@ -351,8 +351,8 @@ int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt
  * search_beam = +inf with max_active_states = 0 is the exact search (scores and arcs equal wf_viterbi's bit for bit).
  * best_score / best_arcs: as wf_viterbi (ties -> lowest arc index).  tot_log (nullable): device fp32 [B], or fp64 [B] with
  * WF_DOUBLE_ACC: log-semiring total score of the pruned lattice (all paths through surviving states).  n_active (nullable):
- * device int32 [B][Tmax+1], surviving states per frame.  k2's own pruning arithmetic (dynamic beams, output_beam applied
- * backwards over the lattice) is parity unpinned: the reference holds no fixture for it; see INTEGRATION.md.            */
+ * device int32 [B][Tmax+1], surviving states per frame.  output_beam: wf_search_lattice below.  k2's own pruning
+ * arithmetic (dynamic beams) is parity unpinned: the reference holds no fixture for it; see INTEGRATION.md.            */
 int wf_search_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B, int32_t V,
                               int32_t max_active_states, int32_t want_log_tot, size_t* bytes);
 int wf_search(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
