@@ -852,13 +852,17 @@ def test_lattice_analysis_call_shapes_on_a_decoding_graph():
     for i, T in enumerate([33, 20]):
         s32, path32 = o.viterbi(g, lp[i], T)
         assert best[i] == float(s32)          # the search's tropical arithmetic is fp32 (k2's lattice arc scores are fp32)
-        np.testing.assert_allclose(tot[i], o.forward(g, lp[i], T)[1], rtol=1e-9)
+        # (:128: the total of the lattice that output_beam = 8 leaves -- oracle.lattice_search states the rule)
+        np.testing.assert_allclose(tot[i], o.lattice_search(g, lp[i], T, np.inf, 8.0)[2], rtol=1e-9)
         assert one_best.labels[i] == [int(g["label"][a]) for a in path32] and one_best.labels[i][-1] == -1
         assert words[i] == [int(g["aux"][a]) for a in path32 if g["aux"][a] > 0]
         assert one_best.get_tot_scores(True, False)[i].item() == float(s32)
     dense = wf.DenseFsaVec(x, torch.tensor([[0, 0, 33], [1, 0, 20]], dtype=torch.int32))
     again = wf.intersect_dense(TLG, dense, 10).get_tot_scores(True, True).cpu().numpy()   # the exact sweep
-    np.testing.assert_allclose(again, tot, rtol=1e-9)
+    whole = wf.get_lattice(x, lens, TLG, search_beam=float("inf"), output_beam=float("inf"), min_active_states=0,
+                           max_active_states=0).get_tot_scores(True, True).cpu().numpy()
+    np.testing.assert_allclose(again, whole, rtol=1e-9)              # nothing pruned: the whole product
+    assert np.all(tot <= whole + 1e-9) and np.all(tot >= best - 1e-4)
 
 
 def test_loss_stats_kernel_matches_the_elementwise_formula():

@@ -335,3 +335,6 @@ def test_get_lattice_applies_output_beam():
         np.testing.assert_allclose(tn[i].item(), o.lattice_search(g, lp[i], Ti, 20.0, 2.0)[2], rtol=1e-9)
         np.testing.assert_allclose(tw[i].item(), o.beam_search(g, lp[i], Ti, 20.0)[2], rtol=1e-6)
     assert torch.equal(decode.one_best_decoding(narrow).scores, decode.one_best_decoding(wide).scores)
+    t32 = narrow.get_tot_scores(False, True)                     # fp32 totals: the same launch, rounded at the end
+    assert t32.dtype == torch.float32
+    np.testing.assert_allclose(t32.cpu().numpy(), tn.cpu().numpy(), rtol=1e-6)
