@@ -762,13 +762,17 @@ __global__ void __launch_bounds__(64) numerator_compile_kernel(NcArgs p) {
     }
     if (!p.done) return;
     // ---- the last workgroup to get here finishes the batch (every workgroup arrives: no one waits for another)
+    // (the hand-off between workgroups inside a launch: this workgroup is one wave; it releases what it stored at agent scope
+    // and waits for that before it takes its ticket; the last arriver acquires before it loads the others' results)
     __shared__ unsigned s_ticket;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (lane == 0) s_ticket = atomicAdd(p.done, 1u);
     __syncthreads();
     if (s_ticket != (unsigned)p.B - 1) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) *p.done = 0;
     const int Bn = p.B, M = p.meta_words;
     int carry = 0, acarry = 0, bad = 0, gmaxS = 0, gmaxA = 0, gmaxlab = -1, ndirect = 0;

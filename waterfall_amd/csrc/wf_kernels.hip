@@ -4475,6 +4475,11 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
 template <typename T> __device__ __forceinline__ T ld_fresh(const T* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Hand-offs between workgroups inside a launch (search_mw_kernel, search_back_kernel): EVERY wave waits for its own
+// stores and atomics before the workgroup's barrier (s_barrier waits for no counter), then one lane releases at agent
+// scope, waits again, and signals; the waiting lane polls relaxed, acquires once, waits, and the workgroup's barrier
+// lets the other waves load.
+__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __global__ void __launch_bounds__(kSearchThreads) search_kernel(SearchArgs p) {
     __shared__ int s_ncand, s_nsurv, s_keepbin, s_narcs, s_bin0;
@@ -4945,11 +4950,13 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
 
     // barrier of the utterance's workgroups; true: the utterance was given up (every lane of every workgroup leaves)
     auto grid_sync = [&]() -> bool {
-        __syncthreads();   // (this workgroup's memory operations have completed)
+        drain_vm();        // every wave: its stores and atomics have completed ...
+        __syncthreads();   // ... before one lane releases them for the whole workgroup
         if (tid == 0) {
             ++nbar;
             const unsigned target = nbar * (unsigned)NW;
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (the XCD's L2 writes back what this workgroup stored)
+            drain_vm();
             atomicAdd(&ctl->bar, 1u);
             long spins = 0;
             bool ab = false;
@@ -4958,7 +4965,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
                 if ((spins & 255) == 0 && (ld_fresh(&ctl->abort) || spins > kSearchSpinLimit)) { ab = true; break; }
             }
             if (ab) atomicExch(&ctl->abort, 1);
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (this compute unit's L1 drops its lines; the wait holds the barrier below for it)
+            drain_vm();
             s_abort = ab || ld_fresh(&ctl->abort);
         }
         __syncthreads();
@@ -4999,7 +5007,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
                     __builtin_amdgcn_s_sleep(16);
                     if ((++spins & 255) == 0 && ld_fresh(&ctl->abort)) { r = 0x7fffffff; break; }
                 }
-                __threadfence();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                drain_vm();
                 s_resume = r;
             }
             __syncthreads();
@@ -5235,9 +5244,11 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
                 if (tid == 0) {
                     ctl->r_nx = nX; ctl->r_base = base; ctl->r_base_prev = base_prev; ctl->r_g = f2ord(G);
                 }
-                __syncthreads();   // (every lane's stores of the solo frames have completed)
+                drain_vm();        // every wave's stores of the solo frames have completed
+                __syncthreads();
                 if (tid == 0) {
-                    __threadfence();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    drain_vm();
                     atomicExch(&ctl->resume_t, over ? 0x7fffffff : t);
                 }
             }
@@ -5382,12 +5393,14 @@ __global__ void __launch_bounds__(kSearchThreads) search_back_kernel(SearchBackA
     // barrier of the utterance's workgroups, bounded as search_mw_kernel's: true = given up (everyone leaves; the second
     // launch walks the utterance with one workgroup)
     auto sync_all = [&]() -> bool {
+        if (multi) drain_vm();
         __syncthreads();
         if (!multi) return false;
         if (tid == 0) {
             ++nbar;
             const unsigned target = nbar * (unsigned)NW;
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            drain_vm();
             atomicAdd(&ctl->bbar, 1u);
             long spins = 0;
             bool ab = false;
@@ -5396,7 +5409,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_back_kernel(SearchBackA
                 if ((spins & 255) == 0 && (ld_fresh(&ctl->babort) || spins > kSearchSpinLimit)) { ab = true; break; }
             }
             if (ab) atomicExch(&ctl->babort, 1);
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_vm();
             s_abort = ab || ld_fresh(&ctl->babort);
         }
         __syncthreads();
