@@ -238,7 +238,12 @@ int wf_compose_fsa_batch(const int32_t* topo_arcs, const int32_t* topo_aux, int3
 /* ---- workspace ------------------------------------------------------------------------------
  * utt2fsa: host [B] FSA index used by utterance i, or NULL for the identity (B == G); a single
  * shared denominator topology (rnnp.py:91-92) is utt2fsa = {0,0,...}.
- * seg: host int32 [B][3] = {sequence index b, start frame, num frames} (models.py:256-258).     */
+ * seg: host int32 [B][3] = {sequence index b, start frame, num frames} (models.py:256-258).  A sequence named by
+ * several segments of one call: the forward-backward entry points (wf_fb_logsum / wf_fb_backward / wf_tot_scores with
+ * WF_DOUBLE_ACC) return WF_EUNSUPPORTED -- their gradient kernels walk one segment per sequence; call them once per
+ * round (round r = the r-th segment of every sequence; utt2fsa selects the round's graphs from the same prepared blob,
+ * gradients of later rounds go to a second box and are added), as the Python drop-in does.  wf_viterbi / wf_search take
+ * such batches as they are.                                                                      */
 /* num_seqs: the first dimension of log_probs (the value the compute calls receive): sizes the seq -> utterance map. */
 int wf_fb_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
                           int32_t B, int32_t num_seqs, int32_t V, uint32_t flags, int32_t need_grad, size_t* bytes);

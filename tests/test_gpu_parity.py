@@ -1323,3 +1323,41 @@ def test_hub_sweep_in_segments_equals_the_single_launch():
     tot7, grad7 = _with_env({"WF_HUB_SEGS": "16:9,10,11,12,13,14,15,16"}, run)
     assert np.array_equal(tot, tot7)
     np.testing.assert_allclose(grad, grad7, rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("topo,den,beam", [("ctc", False, None), ("mmictc", True, None), ("2state", False, 6.0)])
+@pytest.mark.parametrize("reduction", ["sum", "none", "mean"])
+def test_several_supervision_segments_per_sequence(topo, den, beam, reduction):
+    """k2.DenseFsaVec lets several supervision segments name one sequence (models.py:256-261 builds one per sequence):
+    one library call refuses such a batch (WF_EUNSUPPORTED) and the drop-in runs it in rounds; loss and gradient against
+    the oracle, whose gradient adds the segments' posteriors into the sequence's rows."""
+    c = util.random_case(71, topo, B=6, T=48, L=3, P=8, den=den)
+    segs = np.array([[0, 0, 20], [2, 5, 30], [0, 24, 24], [1, 0, 48], [2, 36, 12], [0, 20, 4]], dtype=np.int32)
+    lp = torch.from_numpy(c["lp"][:3]).to(DEV).requires_grad_(True)
+    dense = wf.DenseFsaVec(lp, torch.from_numpy(segs))
+    tl = torch.tensor([3, 3, 3, 3, 3, 3])
+    old = wf.graph._BEAM_MODE
+    wf.set_output_beam_mode("pruned")
+    try:
+        loss = wf.graphloss(c["fsa"], dense, output_beam=beam, reduction=reduction, target_lengths=tl)
+        w = torch.arange(1, 7, dtype=torch.float32, device=DEV) if reduction == "none" else None
+        (loss * w).sum().backward() if reduction == "none" else loss.backward()
+    finally:
+        wf.set_output_beam_mode(old)
+    want, gwant = o.graphloss(c["ographs"], c["lp"][:3], segs, beam, reduction, target_lengths=tl.numpy())
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), want, rtol=TOT_RTOL, atol=TOT_ATOL)
+    if reduction == "none":   # d (sum_i w_i loss_i): the oracle's gradient per utterance, weighted
+        gwant = np.zeros_like(gwant)
+        for i in range(6):
+            gi = o.graphloss([c["ographs"][i]], c["lp"][:3], segs[i:i + 1], beam, "sum")[1]
+            gwant += (i + 1) * gi
+    np.testing.assert_allclose(lp.grad.cpu().numpy(), gwant, atol=GRAD_ATOL * (6 if reduction == "none" else 1))
+    # forward-only entry points take such batches as they are
+    tot = wf.tot_scores(c["fsa"], wf.DenseFsaVec(lp.detach(), torch.from_numpy(segs)), True, True).cpu().numpy()
+    bp = wf.best_path(c["fsa"], wf.DenseFsaVec(lp.detach(), torch.from_numpy(segs)))
+    sr = wf.pruned_search(c["fsa"], wf.DenseFsaVec(lp.detach(), torch.from_numpy(segs)), search_beam=float("inf"),
+                          min_active_states=0, max_active_states=0, log_tot=False)
+    for i in range(6):
+        x, T = c["lp"][segs[i, 0], segs[i, 1]:], int(segs[i, 2])
+        np.testing.assert_allclose(tot[i], o.forward(c["ographs"][i], x, T)[1], rtol=1e-9)
+        assert bp["scores"][i].item() == o.viterbi(c["ographs"][i], x, T)[0] == sr["scores"][i].item()

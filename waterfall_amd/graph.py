@@ -413,6 +413,59 @@ _EAGER_DIRECT = True   # denominators (direct label columns) take the fused call
 
 
 def _graphloss(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double_scores, target_lengths):
+    """graph.py:61-76.  One library call per batch; a batch in which a sequence is named by several supervision segments
+    (k2.DenseFsaVec allows it; models.py:256-261 never builds one) is refused by that call (WF_EUNSUPPORTED: its gradient
+    kernels walk one segment per sequence) and is then run in rounds, see _graphloss_rounds."""
+    try:
+        return _graphloss_once(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double_scores, target_lengths)
+    except _lib.WfError as e:
+        if "more than one segment" not in str(e) or not isinstance(decoding_graph, Fsa):
+            raise
+    return _graphloss_rounds(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double_scores, target_lengths)
+
+
+def _select(graph, idx):
+    """The FSAs of utterances `idx` as a vector over the SAME prepared tables (nothing is copied or prepared again)."""
+    graph.blob_host()
+    u = idx.astype(np.int32) if graph.utt2fsa is None else np.asarray(graph.utt2fsa)[idx].astype(np.int32)
+    v = Fsa(graph.arcs, graph.aux_labels, graph.fsa_arc_offsets, graph.fsa_num_states, utt2fsa=np.ascontiguousarray(u))
+    v._blob_host = graph._blob_host
+    v._blob_dev = graph._blob_dev
+    v._shared_from = graph
+    return v
+
+
+def _in_rounds(graph, dense, fn):
+    """fn(graphs, dense) -> [B'] tensor, applied to round r = the r-th segment of every sequence; results in batch order."""
+    seg = dense.supervision_segments.numpy()
+    B = seg.shape[0]
+    seen, rnd = {}, np.empty(B, dtype=np.int64)
+    for i, q in enumerate(seg[:, 0].tolist()):
+        rnd[i] = seen.get(q, 0)
+        seen[q] = rnd[i] + 1
+    parts, order = [], []
+    for r in range(int(rnd.max()) + 1):
+        idx = np.nonzero(rnd == r)[0]
+        sub = DenseFsaVec(dense.log_probs, dense.supervision_segments[torch.from_numpy(idx)])
+        parts.append(fn(_select(graph, idx), sub))
+        order.append(idx)
+    inv = np.argsort(np.concatenate(order), kind="stable")
+    return torch.cat(parts)[torch.from_numpy(inv).to(parts[0].device)]
+
+
+def _graphloss_rounds(graph, dense, output_beam, reduction, use_double_scores, target_lengths):
+    """Several segments per sequence: round r holds the r-th segment of every sequence (one segment per sequence within a
+    round: the ordinary call), the per-utterance losses are put back in the batch's order and autograd adds the rounds'
+    gradient boxes.  One library call per round."""
+    loss = _in_rounds(graph, dense, lambda g, d: _graphloss_once(g, d, output_beam, 'none', use_double_scores, None))
+    if reduction == 'none':
+        return loss
+    if reduction == 'sum':
+        return loss.sum()
+    return (loss / target_lengths.to(loss.device)).mean()
+
+
+def _graphloss_once(decoding_graph, dense_fsa_vec, output_beam, reduction, use_double_scores, target_lengths):
     """graph.py:61-76: loss = -tot_scores (float32), reduced 'none' | 'sum' | 'mean' (/ target_lengths, then batch mean)."""
     beam = _beam_value(output_beam, decoding_graph if isinstance(decoding_graph, Fsa) else None, dense_fsa_vec, use_double_scores)
     lp = dense_fsa_vec.log_probs
@@ -447,6 +500,15 @@ def graphloss(decoding_graph: Fsa, dense_fsa_vec: DenseFsaVec, output_beam: floa
 def tot_scores(graph: Fsa, dense: DenseFsaVec, log_semiring: bool = True, use_double_scores: bool = False):
     """lattice.get_tot_scores(log_semiring=, use_double_scores=) over the exact intersection
     (utils/lattice_analysis.py:148-149).  No gradient.  Returns float32 [B] (float64 with double)."""
+    try:
+        return _tot_scores_once(graph, dense, log_semiring, use_double_scores)
+    except _lib.WfError as e:
+        if "more than one segment" not in str(e):
+            raise
+    return _in_rounds(graph, dense, lambda g, d: _tot_scores_once(g, d, log_semiring, use_double_scores))
+
+
+def _tot_scores_once(graph, dense, log_semiring, use_double_scores):
     lp, seg, B = _check_inputs(graph, dense)
     lib = _lib.lib()
     dev = lp.device
