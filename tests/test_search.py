@@ -338,3 +338,31 @@ def test_get_lattice_applies_output_beam():
     t32 = narrow.get_tot_scores(False, True)                     # fp32 totals: the same launch, rounded at the end
     assert t32.dtype == torch.float32
     np.testing.assert_allclose(t32.cpu().numpy(), tn.cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("drop", [1, 2, 3])
+def test_a_workgroup_that_never_arrives_is_survived(drop, search_kernel_variant):
+    """The barriers between an utterance's workgroups are bounded: when a partner never arrives (here: the test hook makes
+    the last workgroup leave at once, in the forward kernel (1), the backward one (2) or both) the waiting workgroups give
+    the utterance up after ~0.1 s and the one-workgroup launches redo it -- same results as without the hook."""
+    import os
+    if search_kernel_variant != "four_workgroups_every_frame_shared":
+        pytest.skip("the hook only acts on the multi-workgroup kernels")
+    g, lp, segs, fsa, dense = _big(20_000, B=3, T=25, seed=17)
+    kw = dict(search_beam=9.0, min_active_states=0, max_active_states=0, use_double_scores=True, return_active=True,
+              output_beam=4.0)
+    want = wf.pruned_search(fsa, dense, **kw)
+    os.environ["WF_SEARCH_TEST_DROP"] = str(drop)
+    try:
+        got = wf.pruned_search(fsa, dense, **kw)
+    finally:
+        os.environ.pop("WF_SEARCH_TEST_DROP", None)
+    for k in ("scores", "arcs", "n_active", "lattice_arcs"):
+        assert torch.equal(got[k], want[k]), k
+    np.testing.assert_allclose(got["tot_log"].cpu().numpy(), want["tot_log"].cpu().numpy(), rtol=1e-12)
+    for i in range(3):
+        Ti = int(segs[i, 2])
+        s, path, tl, na = o.lattice_search(g, lp[i], Ti, 9.0, 4.0)
+        assert got["scores"][i].item() == s and got["lattice_arcs"][i].item() == na
+        if np.isfinite(tl):
+            np.testing.assert_allclose(got["tot_log"][i].item(), tl, rtol=1e-9)

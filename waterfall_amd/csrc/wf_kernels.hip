@@ -4441,6 +4441,8 @@ struct SearchArgs {
     struct SearchCtl* ctl;       // [B], zeroed before the launch
     const int32_t* redo;         // search_kernel after search_mw_kernel: [B] stride of SearchCtl, run only the utterances whose flag is set
     int redo_stride;
+    int test_drop;               // test aid (WF_SEARCH_TEST_DROP, bit 0: search_mw_kernel, bit 1: search_back_kernel): the utterance's last workgroup leaves at once, as if it had never
+                                 // become resident -- its partners' barrier runs out and the one-workgroup launch redoes the utterance
 };
 
 // Per-utterance control block of search_mw_kernel (device memory, zero at launch): the barrier counter of the utterance's
@@ -4947,6 +4949,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_mw_kernel(SearchArgs p)
     const float ninf = -INFINITY;
     const int solo_max = max(p.solo_max, 2);
     unsigned nbar = 0;
+    if ((p.test_drop & 1) && g == NW - 1) return;
 
     // barrier of the utterance's workgroups; true: the utterance was given up (every lane of every workgroup leaves)
     auto grid_sync = [&]() -> bool {
@@ -5357,6 +5360,7 @@ struct SearchBackArgs {
     int wgs, B, solo_max;        // workgroups per utterance (workgroup b serves utterance b % B, as search_mw_kernel)
     SearchCtl* ctl;              // [B] (wgs > 1, or redo)
     int redo;                    // second launch, one workgroup per utterance: only the utterances whose babort is set
+    int test_drop;               // test aid, as SearchArgs::test_drop
 };
 
 constexpr int kBackRecs = 2;     // records per lane in flight (the frame is a chain of dependent loads: overlap two)
@@ -5390,6 +5394,7 @@ __global__ void __launch_bounds__(kSearchThreads) search_back_kernel(SearchBackA
     if (!multi && g != 0) return;
     const int NW = multi ? p.wgs : 1;
     unsigned nbar = 0;
+    if ((p.test_drop & 2) && multi && g == NW - 1) return;
     // barrier of the utterance's workgroups, bounded as search_mw_kernel's: true = given up (everyone leaves; the second
     // launch walks the utterance with one workgroup)
     auto sync_all = [&]() -> bool {
@@ -7599,6 +7604,7 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
         // work) the one-workgroup kernel redoes in the second launch, which otherwise exits at once
         HIP_TRY(hipMemsetAsync(ws + S.off_ctl, 0, sizeof(SearchCtl) * (size_t)B, st));
         a.wgs = S.wgs; a.B = B; a.solo_max = env_int("WF_SEARCH_SOLO_MAX", 256);
+        a.test_drop = env_int("WF_SEARCH_TEST_DROP", 0);
         a.ctl = (SearchCtl*)(ws + S.off_ctl);
         hipLaunchKernelGGL(search_mw_kernel, dim3(B * S.wgs), dim3(kSearchThreads), 0, st, a);
         a.redo = &a.ctl[0].abort;
@@ -7619,9 +7625,9 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
         b.lattice_arcs = (long long*)lattice_arcs;
         b.wgs = 1; b.B = B;
         if (S.wgs > 1) {   // (the control blocks were zeroed before the forward launch)
-            b.wgs = S.wgs; b.ctl = a.ctl; b.solo_max = a.solo_max;
+            b.wgs = S.wgs; b.ctl = a.ctl; b.solo_max = a.solo_max; b.test_drop = a.test_drop;
             hipLaunchKernelGGL(search_back_kernel, dim3(B * S.wgs), dim3(kSearchThreads), 0, st, b);
-            b.wgs = 1; b.redo = 1;   // what the barrier gave up on: one workgroup, from the start
+            b.wgs = 1; b.redo = 1; b.test_drop = 0;   // what the barrier gave up on: one workgroup, from the start
         }
         hipLaunchKernelGGL(search_back_kernel, dim3(B), dim3(kSearchThreads), 0, st, b);
     }
