@@ -366,3 +366,21 @@ def test_a_workgroup_that_never_arrives_is_survived(drop, search_kernel_variant)
         assert got["scores"][i].item() == s and got["lattice_arcs"][i].item() == na
         if np.isfinite(tl):
             np.testing.assert_allclose(got["tot_log"][i].item(), tl, rtol=1e-9)
+
+
+def test_output_beam_with_zero_frame_segments():
+    """A segment of 0 frames: the lattice is the start state's final arcs (if any)."""
+    arcs = [(0, 1, 1, -0.5), (0, 2, -1, -0.25), (1, 1, 1, -0.1), (1, 2, -1, -0.75)]
+    fsa = wf.create_fsa_vec([wf.Fsa.from_arcs(arcs, 3)] * 3)
+    lp = torch.log_softmax(torch.randn(3, 6, 4, generator=torch.Generator().manual_seed(2)), -1)
+    segs = torch.tensor([[0, 0, 0], [1, 2, 4], [2, 6, 0]], dtype=torch.int32)
+    dense = wf.DenseFsaVec(lp.to(DEV), segs)
+    out = wf.pruned_search(fsa, dense, search_beam=5.0, min_active_states=0, max_active_states=0, use_double_scores=True,
+                           output_beam=3.0)
+    g = fsa.as_oracle_graphs()
+    for i in range(3):
+        b, st, T = (int(x) for x in segs[i])
+        s, path, tl, na = o.lattice_search(g[i], lp[b, st:].numpy(), T, 5.0, 3.0)
+        assert out["scores"][i].item() == s and out["lattice_arcs"][i].item() == na
+        np.testing.assert_allclose(out["tot_log"][i].item(), tl, rtol=1e-9)
+    assert out["scores"][0].item() == -0.25 and out["lattice_arcs"][0].item() == 1
