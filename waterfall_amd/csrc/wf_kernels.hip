@@ -7543,7 +7543,7 @@ extern "C" int wf_search_lattice_workspace_bytes(const void* graph_host, const i
                                                  int32_t V, int32_t max_active_states, size_t* bytes) {
     if (!bytes) return wf_fail(WF_EINVAL, "null bytes");
     SearchPlan S;
-    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, true, true, &S);
+    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, false, true, &S);
     if (rc) return rc;
     *bytes = S.total + 256;
     return WF_OK;
@@ -7562,25 +7562,27 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
     int rc = check_segments("wf_search", seg, B, num_seqs, Tmax);
     if (rc) return rc;
     SearchPlan S;
-    rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, tot_log != nullptr, lattice, &S);
+    // (with the lattice pass the total comes from search_back_kernel: the forward kernels skip their log-semiring pass)
+    const bool fwd_log = tot_log != nullptr && !lattice;
+    rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, fwd_log, lattice, &S);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + S.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, S.total + 256);
     rc = upload_tables(S.P, ws, nullptr, 0, st);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ws + S.off_best, 0, 8 * (size_t)S.nstates, st));
-    if (tot_log) HIP_TRY(hipMemsetAsync(ws + S.off_lsum, 0, 8 * (size_t)S.nstates, st));
+    if (fwd_log) HIP_TRY(hipMemsetAsync(ws + S.off_lsum, 0, 8 * (size_t)S.nstates, st));
     SearchArgs a{};
     a.blob = (const int32_t*)graph_dev;
     a.utt = (const int64_t*)(ws + S.P.off_utt);
     a.tab = a.utt + (size_t)B * WF_U_WORDS;
     a.lp = log_probs; a.strideB = strideB; a.strideT = strideT;
     a.best = (unsigned long long*)(ws + S.off_best);
-    a.lsum = tot_log ? (double*)(ws + S.off_lsum) : nullptr;
+    a.lsum = fwd_log ? (double*)(ws + S.off_lsum) : nullptr;
     a.slot = (int32_t*)(ws + S.off_slot);
     a.cand = (int32_t*)(ws + S.off_cand);
     a.cpk = (unsigned long long*)(ws + S.off_cpk);
-    a.cls = tot_log ? (double*)(ws + S.off_cls) : nullptr;
+    a.cls = fwd_log ? (double*)(ws + S.off_cls) : nullptr;
     a.arcown = (int32_t*)(ws + S.off_arcown);
     a.xstate = (int32_t*)(ws + S.off_xs);
     a.xscore = (float*)(ws + S.off_xv);
@@ -7590,7 +7592,7 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
     a.nstates = S.nstates;
     a.beam = search_beam; a.max_active = max_active_states; a.min_active = min_active_states;
     a.best_score = best_score; a.best_arcs = best_arcs; a.Tmax = Tmax;
-    a.tot_log = tot_log; a.tot_double = (flags & WF_DOUBLE_ACC) ? 1 : 0;
+    a.tot_log = fwd_log ? tot_log : nullptr; a.tot_double = (flags & WF_DOUBLE_ACC) ? 1 : 0;
     a.n_active = n_active;
     if (lattice) {
         a.rinfo = (int4*)(ws + S.off_rinfo);
