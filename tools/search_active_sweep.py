@@ -1,6 +1,6 @@
 """wf_search at realistic active-state counts: cfg5's S = 10^6 graph, B = 8, T = 500, search_beam 20,
 the planted path's logit boost chosen so that the mean number of active states is about 500 / 2 000 / 5 000.
-Usage: python tools/search_active_sweep.py [peak ...]"""
+Usage: [SWEEP_B=1] python tools/search_active_sweep.py [peak ...]"""
 import sys
 import time
 sys.path.insert(0, ".")
@@ -21,7 +21,8 @@ def timed(f, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3, out
 
 
-S, B, T, V = 1_000_000, 8, 500, 5001
+import os
+S, B, T, V = 1_000_000, int(os.environ.get("SWEEP_B", "8")), 500, 5001   # (SWEEP_B=1: the reference's lattice_analysis.py decodes one utterance at a time)
 for peak in [float(x) for x in sys.argv[1:]] or [10.0, 6.0, 5.0, 4.0, 3.0]:
     g, fsa, lp, dense = cfg5_workload(dev, S, B, T, V, peaked=True, peak=peak)
     ms_exact, exact = timed(lambda: wf.best_path(fsa, dense))
