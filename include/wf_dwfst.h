@@ -382,6 +382,25 @@ int wf_search_lattice(const void* graph_host, const void* graph_dev, const int32
                       uint32_t flags, float* best_score, int32_t* best_arcs, void* tot_log, int64_t* lattice_arcs,
                       int32_t* n_active, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ... and the lattice restricted to a word sequence per utterance: `latticeW = k2.connect(k2.compose(lattice, W))` with
+ * W = k2.linear_fst(words, words), and latticeW.get_tot_scores(True, True) / (True, False)
+ * (utils/lattice_analysis.py:137-139,161-162: the numerators of the script's three ratios).  One more launch after the two
+ * of wf_search_lattice walks the output lattice backwards over cells (record, words consumed): an arc with aux label 0 keeps
+ * the count, one whose aux label is the next word advances it, any other aux label leaves the lattice.  aux_dev: device
+ * int32, one aux label per arc of the FsaVec (0 = epsilon, -1 on final arcs); words / word_off: host, utterance i's word
+ * ids (> 0) are words[word_off[i] .. word_off[i + 1]).  tot_words (fp32 [B], fp64 with WF_DOUBLE_ACC): log-semiring total
+ * over the lattice's paths that spell the words; best_words (fp32 [B]): the tropical one; -inf when there is none.
+ * Everything else as wf_search_lattice.  Rule: oracle.lattice_words (parity unpinned against k2, as above).            */
+int wf_search_lattice_words_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int32_t B,
+                                            int32_t V, int32_t max_active_states, const int32_t* words,
+                                            const int32_t* word_off, size_t* bytes);
+int wf_search_lattice_words(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
+                            int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B,
+                            int32_t Tmax, float search_beam, float output_beam, int32_t min_active_states,
+                            int32_t max_active_states, uint32_t flags, const int32_t* aux_dev, const int32_t* words,
+                            const int32_t* word_off, float* best_score, int32_t* best_arcs, void* tot_log, void* tot_words,
+                            float* best_words, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- multi-GPU: the buffer of the one fused all-reduce per step (the reference gets these numbers
  * from Lightning's DDP reductions around graph.py:66-76).  out[0] = -(sum of the finite tot[i]), out[1] = n_frames,
  * out[2] = number of infeasible utterances (tot = -inf); device pointers, one small launch on `stream`.            */

@@ -358,6 +358,62 @@ def lattice_search(g, lp, T, search_beam=np.inf, output_beam=np.inf):
     return score, path, float(bl[0]), narcs
 
 
+def lattice_words(g, lp, T, words, search_beam=np.inf, output_beam=np.inf):
+    """lattice_search's output lattice restricted to the paths whose word sequence is `words`: the restatement of
+    `latticeW = k2.connect(k2.compose(lattice, W))` with W = k2.linear_fst(words, words) and of its
+    get_tot_scores(True, True) / (True, False) (utils/lattice_analysis.py:137-139,161-162).  g["aux"]: word id per arc
+    (0 = epsilon, -1 on final arcs).  Returns (tot_log fp64, best fp32): log-semiring and tropical totals over those paths
+    (-inf when the lattice holds none).  [k2-upstream, parity unpinned]"""
+    fr = []
+    score, path, _, _ = beam_search(g, lp, T, search_beam, frames=fr)
+    if not np.isfinite(score):
+        return NEG_INF, np.float32(NEG_INF)
+    S = g["num_states"]
+    n = len(words)
+    em, fin = _split(g)
+    src, dst, aux = g["src"][em], g["dst"][em], g["aux"][em]
+    thresh = np.float32(score - np.float32(output_beam)) if np.isfinite(output_beam) else np.float32(NEG_INF)
+    fsrc, fw = g["src"][fin], g["score"][fin].astype(np.float32)
+    aT = fr[T]
+    with np.errstate(invalid="ignore"):
+        live = np.isfinite(aT[fsrc]) & np.isfinite(fw)
+        bt = np.full(S, NEG_INF, dtype=np.float32)
+        np.maximum.at(bt, fsrc[live], fw[live])
+        kept = live & ((aT[fsrc] + fw).astype(np.float32) >= thresh)
+    L = np.full((S, n + 1), NEG_INF, dtype=np.float64)       # log-semiring backward score of (state, words consumed)
+    M = np.full((S, n + 1), NEG_INF, dtype=np.float32)       # tropical
+    L[:, n] = _seg_lse(fw[kept].astype(np.float64), fsrc[kept], S, np.float64)
+    np.maximum.at(M[:, n], fsrc[kept], fw[kept])
+    # arcs that consume word k (k + 1 afterwards), per k; epsilon arcs keep k
+    eps = aux == 0
+    for t in range(T - 1, -1, -1):
+        x = arc_scores(g, lp[t])
+        a0, a1 = fr[t], fr[t + 1]
+        with np.errstate(invalid="ignore"):
+            vb = (x + bt[dst]).astype(np.float32)
+            live = np.isfinite(a0[src]) & np.isfinite(a1[dst]) & np.isfinite(vb)
+            kept = live & ((a0[src] + vb).astype(np.float32) >= thresh)
+            nbt = np.full(S, NEG_INF, dtype=np.float32)
+            np.maximum.at(nbt, src[live], vb[live])
+            nL = np.full((S, n + 1), NEG_INF, dtype=np.float64)
+            nM = np.full((S, n + 1), NEG_INF, dtype=np.float32)
+            for k in range(n + 1):
+                sel = kept & eps
+                vals = [x[sel].astype(np.float64) + L[dst[sel], k]]
+                valm = [(x[sel] + M[dst[sel], k]).astype(np.float32)]
+                srcs = [src[sel]]
+                if k < n:
+                    sw = kept & (aux == words[k])
+                    vals.append(x[sw].astype(np.float64) + L[dst[sw], k + 1])
+                    valm.append((x[sw] + M[dst[sw], k + 1]).astype(np.float32))
+                    srcs.append(src[sw])
+                v, vm, ss = np.concatenate(vals), np.concatenate(valm), np.concatenate(srcs)
+                nL[:, k] = _seg_lse(v, ss, S, np.float64)
+                np.maximum.at(nM[:, k], ss, vm)
+        bt, L, M = nbt, nL, nM
+    return float(L[0, 0]), np.float32(M[0, 0])
+
+
 def graphloss(graphs, lp, segs, output_beam=None, reduction="sum", target_lengths=None,
               dtype=np.float64):
     """graph.py:79-118 restated: returns (loss, d loss / d lp [B,T,V]).

@@ -251,3 +251,36 @@ def test_lattice_search_restatement_against_prune_mask(topo, den):
             np.testing.assert_allclose(tl, o.forward(g, lp, T, True, keep=keep)[1], rtol=1e-12)
             assert 0 < na - int(keep.sum()) <= int(fin.sum())
             assert tl <= o.lattice_search(g, lp, T, np.inf, np.inf)[2] + 1e-12
+
+
+def test_lattice_words_restatement_against_the_composed_graph():
+    """oracle.lattice_words (the lattice restricted to a word sequence, what wf_search_lattice_words is tested against) with
+    nothing pruned against an independent route: decode.compose_words builds `connect(compose(TLG, W))` as a graph and the
+    pinned `forward` / `viterbi` run on it (utils/lattice_analysis.py:139-149)."""
+    import torch
+    import waterfall_amd as wf
+    from waterfall_amd import decode
+    from waterfall_amd.synth import synth_decoding_graph
+    g = synth_decoding_graph(3, 300, 20)
+    rng = np.random.default_rng(0)
+    em = g["label"] >= 0
+    g["aux"] = np.where(em, np.where(rng.random(em.size) < 0.3, rng.integers(1, 5, em.size), 0), -1).astype(np.int32)
+    arcs = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
+    TLG = wf.Fsa(arcs, g["aux"], [0, arcs.shape[0]], [g["num_states"]])
+    T = 12
+    lp = torch.log_softmax(torch.randn(T, 20, generator=torch.Generator().manual_seed(1)) * 2, -1).numpy()
+    s, path, tl, _ = o.lattice_search(g, lp, T)
+    words = [int(g["aux"][a]) for a in path if g["aux"][a] > 0]
+    for ws in (words, words[:-1], words + [1], []):
+        tw, bw = o.lattice_words(g, lp, T, ws)
+        gw = decode.compose_words(TLG, ws).as_oracle_graphs()[0]
+        fw, vb = o.forward(gw, lp, T)[1], o.viterbi(gw, lp, T)[0]
+        if np.isfinite(fw):
+            np.testing.assert_allclose(tw, fw, rtol=1e-12)
+        else:
+            assert tw == -np.inf
+        # (tropical totals: the backward sum associates from the right, viterbi from the left -- fp32 rounding apart)
+        assert (bw == vb) if not np.isfinite(vb) else abs(float(bw) - float(vb)) <= 1e-5 * abs(float(vb))
+        assert tw <= tl + 1e-9
+    np.testing.assert_allclose(o.lattice_words(g, lp, T, words)[1], s, rtol=1e-6)   # the best path spells its own words
+    assert decode.compose_words(TLG, [4] * 15).arcs.shape[0] == 0   # longer than any path: an empty graph

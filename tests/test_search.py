@@ -384,3 +384,77 @@ def test_output_beam_with_zero_frame_segments():
         assert out["scores"][i].item() == s and out["lattice_arcs"][i].item() == na
         np.testing.assert_allclose(out["tot_log"][i].item(), tl, rtol=1e-9)
     assert out["scores"][0].item() == -0.25 and out["lattice_arcs"][0].item() == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# lattice_analysis.py:137-172: the lattice (and the decoding graph) restricted to a word sequence
+# ---------------------------------------------------------------------------------------------
+
+def _word_graph(S, B, T, seed, V=301):
+    g, lp, segs, fsa, dense = _big(S, B=B, T=T, seed=seed, V=V)
+    rng = np.random.default_rng(seed)
+    g["aux"] = np.where(g["label"] >= 0, np.where(rng.random(g["label"].size) < 0.25, rng.integers(1, 40, g["label"].size), 0),
+                        -1).astype(np.int32)
+    arcs_ = np.stack([g["src"], g["dst"], g["label"], g["score"].view(np.int32)], 1).astype(np.int32)
+    one = wf.Fsa(arcs_, g["aux"], [0, arcs_.shape[0]], [g["num_states"]])
+    return g, lp, segs, one, wf.create_fsa_vec([one] * B), dense
+
+
+@pytest.mark.parametrize("search_beam,output_beam", [(7.0, 3.0), (INF, 5.0), (9.0, INF)])
+def test_lattice_restricted_to_words_against_oracle(search_beam, output_beam):
+    g, lp, segs, one, fsa, dense = _word_graph(12_001, B=4, T=26, seed=31)
+    kw = dict(search_beam=search_beam, output_beam=output_beam, min_active_states=0, max_active_states=0)
+    base = wf.pruned_search(fsa, dense, use_double_scores=True, **kw)
+    words = [[w for w in ws] for ws in base["aux_labels"]]                 # the best path's words
+    words[1] = words[1][:-1] + [39, 39, 39] if words[1] else [39]            # a sequence the lattice may not hold
+    out = wf.lattice_words(fsa, dense, words, **kw)
+    assert torch.equal(out["scores"], base["scores"]) and torch.equal(out["arcs"], base["arcs"])
+    np.testing.assert_allclose(out["tot_log"].cpu().numpy(), base["tot_log"].cpu().numpy(), rtol=1e-12)
+    for i in range(4):
+        Ti = int(segs[i, 2])
+        tw, bw = o.lattice_words(g, lp[i], Ti, words[i], search_beam, output_beam)
+        assert out["best_words"][i].item() == bw
+        if np.isfinite(tw):
+            np.testing.assert_allclose(out["tot_words"][i].item(), tw, rtol=1e-9)
+        else:
+            assert out["tot_words"][i].item() == -np.inf
+        if i != 1 and np.isfinite(base["scores"][i].item()):
+            # the best path spells its own words (backward association of the fp32 sum: rounding apart)
+            np.testing.assert_allclose(bw, base["scores"][i].item(), rtol=1e-6)
+            assert tw <= base["tot_log"][i].item() + 1e-9
+
+
+def test_lattice_analysis_ratios_with_the_reference_calls():
+    """utils/lattice_analysis.py:125-172 with the same names: the three ratios of analyse_one."""
+    import waterfall_amd as k2
+    g, lp, segs, TLG, _, _ = _word_graph(12_001, B=1, T=30, seed=33)
+    log_prob = torch.from_numpy(lp[:1]).to(DEV)
+    log_prob_len = torch.tensor([30])
+    dense_fsa_vec = k2.DenseFsaVec(log_prob, torch.tensor([[0, 0, 30]], dtype=torch.int32))
+    lattice = k2.get_lattice(log_prob, log_prob_len, TLG, search_beam=12.0, output_beam=6.0, min_active_states=0,
+                             max_active_states=0)
+    lattice = k2.invert(k2.invert(lattice))
+    lattice_total_score = lattice.get_tot_scores(True, True)
+    one_best = k2.one_best_decoding(lattice)
+    one_best_aux_label = k2.get_aux_labels(one_best)
+    W = k2.linear_fst(one_best_aux_label, one_best_aux_label)
+    W = k2.arc_sort(W)
+    latticeW = k2.connect(k2.compose(lattice, W))
+    TLGW = k2.connect(k2.compose(TLG, W))
+    ETLGW = k2.intersect_dense(TLGW, dense_fsa_vec, 10)
+    TLG_W_total_score = ETLGW.get_tot_scores(True, True)
+    lattice_W_total_score = latticeW.get_tot_scores(True, True)
+    lattice_W_best_score = latticeW.get_tot_scores(True, False)
+    r1 = np.exp((lattice_W_total_score - lattice_total_score).item())
+    r2 = np.exp((lattice_W_total_score - TLG_W_total_score).item())
+    r3 = np.exp((lattice_W_best_score - lattice_W_total_score).item())
+    assert 0 < r1 <= 1 + 1e-9 and 0 < r2 <= 1 + 1e-9 and 0 < r3 <= 1 + 1e-9
+    words = one_best_aux_label[0]
+    tw, bw = o.lattice_words(g, lp[0], 30, words, 12.0, 6.0)
+    np.testing.assert_allclose(lattice_W_total_score.item(), tw, rtol=1e-9)
+    assert lattice_W_best_score.item() == float(bw)
+    np.testing.assert_allclose(float(bw), one_best.get_tot_scores(True, False)[0].item(), rtol=1e-6)
+    gw = TLGW.as_oracle_graphs()[0]
+    np.testing.assert_allclose(TLG_W_total_score.item(), o.forward(gw, lp[0], 30)[1], rtol=1e-9)
+    np.testing.assert_allclose(TLG_W_total_score.item(), o.lattice_words(g, lp[0], 30, words)[0], rtol=1e-9)   # two routes
+    np.testing.assert_allclose(lattice_total_score.item(), o.lattice_search(g, lp[0], 30, 12.0, 6.0)[2], rtol=1e-9)

@@ -1,5 +1,6 @@
 """Randomised parity run (GPU) of the beam-pruned search wf_search against oracle.beam_search, and of wf_search_lattice
-(the search followed by get_lattice's output_beam) against oracle.lattice_search: random graphs (skewed
+(the search followed by get_lattice's output_beam) against oracle.lattice_search, and of wf_search_lattice_words against
+oracle.lattice_words: random graphs (skewed
 out-degrees, states with thousands of arcs, fan-in hubs, dead ends), quantised weights and emissions (many exact ties:
 the lowest-arc-index rule and the `>= best - beam` boundary are hit all the time), random beams and lengths.
 usage: python tools/fuzz_search.py [cases] [seed] [max_states]   (test infrastructure: imports oracle/)"""
@@ -108,6 +109,31 @@ for case in range(n):
                 why.append(f"lattice tot[{i}] {ltot[i]} != {tl} (output_beam {ob})")
         elif ltot[i] != -np.inf:
             why.append(f"lattice tot[{i}] {ltot[i]} != -inf")
+    # ... and that lattice restricted to a word sequence (wf_search_lattice_words) against oracle.lattice_words: the best
+    # path's words (aux labels: the arc labels here, 0 = epsilon), sometimes cut short or with a wrong word in them
+    words = []
+    for ws in lat["aux_labels"]:
+        ws = list(ws)
+        r = rng.integers(4)
+        if r == 1 and ws:
+            ws = ws[:-1]
+        elif r == 2:
+            ws = ws + [int(rng.integers(1, V + 1))]
+        elif r == 3 and ws:
+            ws[int(rng.integers(len(ws)))] = int(rng.integers(1, V + 1))
+        words.append(ws)
+    lw = wf.lattice_words(fsa, dense, words, search_beam=beam, output_beam=ob, min_active_states=0, max_active_states=0)
+    tw_, bw_ = lw["tot_words"].cpu().numpy(), lw["best_words"].cpu().numpy()
+    for i, g in enumerate(gs):
+        Ti = int(segs[i, 2])
+        tw, bw = o.lattice_words(g, lp[i], Ti, words[i], beam, ob)
+        if not (bw_[i] == bw):
+            why.append(f"best_words[{i}] {bw_[i]} != {bw}")
+        if np.isfinite(tw):
+            if not np.isclose(tw_[i], tw, rtol=1e-9, atol=1e-9):
+                why.append(f"tot_words[{i}] {tw_[i]} != {tw}")
+        elif tw_[i] != -np.inf:
+            why.append(f"tot_words[{i}] {tw_[i]} != -inf")
     # active-state limits: properties only (the oracle states the beam rule alone)
     cap = int(rng.integers(1, 300))
     lim = wf.pruned_search(fsa, dense, search_beam=beam, min_active_states=0, max_active_states=cap, return_active=True)

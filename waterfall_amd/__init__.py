@@ -14,12 +14,13 @@ from . import dist
 from . import compile
 from .lang import Lang, write_lang_dir
 from .decode import (DenseLattice, OneBest, get_lattice, intersect_dense, one_best_decoding, shortest_path,
-                     get_aux_labels)
+                     get_aux_labels, linear_fst, connect, invert, compose_words, DenseLatticeW)
+from .graph import lattice_words
 from .topology import build_topology, topology_text, Topology, TOPOLOGIES
 
 __all__ = [
     "Fsa", "DenseFsaVec", "create_fsa_vec", "GraphLoss", "graphloss", "graphloss_num_den", "tot_scores", "best_path", "pruned_search", "set_output_beam_mode", "set_eager_gradient", "set_num_den_overlap", "manual_ctc", "dist", "Lang", "write_lang_dir", "DenseLattice", "OneBest", "get_lattice", "intersect_dense",
-    "one_best_decoding", "shortest_path", "get_aux_labels",
+    "one_best_decoding", "shortest_path", "get_aux_labels", "linear_fst", "connect", "invert", "compose_words", "DenseLatticeW", "lattice_words",
     "linear_fsa", "remove_epsilon_and_add_self_loops", "arc_sort", "compose", "compile_ctc_k2_graphs",
     "build_topology", "topology_text", "Topology", "TOPOLOGIES",
 ]

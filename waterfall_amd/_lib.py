@@ -87,6 +87,9 @@ _SIGS = {
     "wf_search": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, C.c_float, _i32, _i32, _u32, _p, _p, _p, _p,
                             _p, _sz, _p]),
     "wf_search_lattice_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, C.POINTER(_sz)]),
+    "wf_search_lattice_words_workspace_bytes": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, C.POINTER(_sz)]),
+    "wf_search_lattice_words": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, C.c_float, C.c_float, _i32,
+                                          _i32, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "wf_search_lattice": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, C.c_float, C.c_float, _i32, _i32,
                                     _u32, _p, _p, _p, _p, _p, _p, _sz, _p]),
 }

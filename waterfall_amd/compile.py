@@ -112,7 +112,7 @@ def _topo_tables(topo):
     return tab
 
 
-def compose(topo, b, treat_epsilons_specially=False):
+def compose(topo, b, treat_epsilons_specially=None):
     """k2.compose(topo, linear_with_self_loops, treat_epsilons_specially=False) (models.py:269-270), for the whole
     batch in one native call (wf_compose_linear_batch, include/wf_dwfst.h).
 
@@ -122,6 +122,9 @@ def compose(topo, b, treat_epsilons_specially=False):
     (q,i) -> (q',i) if ph == 0 and (q,i) -> (q',i+1) if ph == b[i]; final arcs from (q, L) when q is
     final.  Output labels = tokens, aux_labels = phones.
     """
+    from . import decode as _decode
+    if isinstance(b, _decode.WordFst):   # k2.compose(lattice, W) / k2.compose(TLG, W) of utils/lattice_analysis.py:139-145
+        return _decode.compose(topo, b)
     if treat_epsilons_specially:
         raise NotImplementedError("the reference always composes with treat_epsilons_specially=False")
     if isinstance(b, Fsa):

@@ -5569,6 +5569,148 @@ __global__ void __launch_bounds__(kSearchThreads) search_back_kernel(SearchBackA
 }
 
 // ------------------------------------------------------------------------------------------
+// search_words_kernel: `latticeW = k2.connect(k2.compose(lattice, W))` with W = k2.linear_fst(words, words) and its
+// get_tot_scores (utils/lattice_analysis.py:137-139,161-162), after search_back_kernel: the output lattice restricted
+// to the paths whose non-epsilon aux labels spell the utterance's word sequence.  Cell (record, k words consumed):
+// L = log-semiring backward score (fp64), M = tropical (fp32); an arc of the lattice (kept by output_beam: the test of
+// search_back_kernel, from its bt) with aux 0 goes to (dst, k), with aux = words[k] to (dst, k + 1), any other aux
+// nowhere; frame T starts from search_back_kernel's values at k = n.  Two frames of cells per utterance (ring by frame
+// parity), one lane per cell, one workgroup per utterance; the start record's cell k = 0 holds the two totals.
+// ------------------------------------------------------------------------------------------
+struct SearchWordsArgs {
+    SearchBackArgs b;            // (bt / bl: what search_back_kernel left)
+    const int32_t* aux;          // device, per arc of the FsaVec (0 = epsilon, -1 on final arcs)
+    const int64_t* woff;         // [B] first cell of the utterance's ring
+    const int32_t* wtab;         // [B][wstride]: n, then the n word ids
+    int wstride;
+    double* wl;
+    float* wt;
+    void* tot_w;                 // fp32 / fp64 [B] (b.tot_double)
+    float* best_w;               // [B]
+};
+
+__global__ void __launch_bounds__(kSearchThreads) search_words_kernel(SearchWordsArgs q) {
+    __shared__ int s_klo[2], s_khi[2];   // word counts that have a finite cell, per frame parity: the others are skipped
+    const SearchBackArgs& p = q.b;
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
+    const int64_t* R = p.tab + (int64_t)u * WF_SR_WORDS;
+    const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
+    const int T = (int)U[WF_U_T];
+    const float ninf = -INFINITY;
+    const float best = p.best_score[u];
+    auto put = [&](double tot, float bw) {
+        if (p.tot_double) ((double*)q.tot_w)[u] = tot; else ((float*)q.tot_w)[u] = (float)tot;
+        q.best_w[u] = bw;
+    };
+    if (!(best > ninf)) {
+        if (tid == 0) put(-INFINITY, ninf);
+        return;
+    }
+    const float thresh = best - p.output_beam;
+    const int direct = I[WF_I_DIRECT];
+    const int4* orec = (const int4*)(p.blob + I[WF_I_OUT_REC]);
+    const int32_t* labels = p.blob + I[WF_I_LABELS];
+    const int32_t* aux = q.aux + I[WF_I_ARC_BASE];
+    int32_t* slot_a = p.slot + R[WF_SR_SOFF];
+    int32_t* slot_b = p.slot2 + R[WF_SR_SOFF];
+    auto slot_of = [&](int t) -> int32_t* { return ((T - t) & 1) ? slot_b : slot_a; };
+    const int4* rinfo = p.rinfo + R[WF_SR_AOFF];
+    const float* bt = p.bt + R[WF_SR_AOFF];
+    const double* bl = p.bl + R[WF_SR_AOFF];
+    const int64_t* ftab = p.ftab + (int64_t)u * p.ftab_stride;
+    const float* lp0 = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
+    const int32_t* W = q.wtab + (int64_t)u * q.wstride;
+    const int n = W[0], N1 = n + 1;
+    ++W;
+    const int64_t cap = R[WF_SR_CAP];
+    double* Lr[2] = {q.wl + q.woff[u], q.wl + q.woff[u] + cap * N1};
+    float* Mr[2] = {q.wt + q.woff[u], q.wt + q.woff[u] + cap * N1};
+    // ---------------- frame T
+    {
+        const int64_t b1 = ftab[T];
+        const int n1 = (int)(ftab[T + 1] - b1);
+        int32_t* slot = slot_of(T);
+        double* L = Lr[(T - T) & 1];
+        float* M = Mr[(T - T) & 1];
+        if (tid == 0) { s_klo[0] = n; s_khi[0] = n; s_klo[1] = 0x7fffffff; s_khi[1] = -1; }
+        for (int64_t x = tid; x < (int64_t)n1 * N1; x += kSearchThreads) {
+            const int i = (int)(x / N1), k = (int)(x % N1);
+            const double l = bl[b1 + i];
+            const bool end = k == n && l > -INFINITY;
+            L[x] = end ? l : -INFINITY;
+            M[x] = end ? bt[b1 + i] : ninf;
+            if (k == 0) slot[rinfo[b1 + i].x] = (int)(b1 + i);
+        }
+        __syncthreads();
+    }
+    // ---------------- frames T - 1 .. 0
+    for (int t = T - 1; t >= 0; --t) {
+        const int64_t b0 = ftab[t], b1 = ftab[t + 1];
+        const int n0 = (int)(b1 - b0), n1 = (int)(ftab[t + 2] - b1);
+        const float* erow = lp0 + (int64_t)t * p.strideT;
+        const int32_t* slot1 = slot_of(t + 1);
+        int32_t* slot0 = slot_of(t);
+        const double* Ln = Lr[(T - t - 1) & 1];
+        const float* Mn = Mr[(T - t - 1) & 1];
+        double* L = Lr[(T - t) & 1];
+        float* M = Mr[(T - t) & 1];
+        const int pn = (T - t - 1) & 1, pc = (T - t) & 1;
+        if (s_khi[pn] < 0) {   // (uniform) no cell of frame t + 1 is finite: the lattice holds no path with these words
+            if (tid == 0) put(-INFINITY, ninf);
+            return;
+        }
+        const int klo = s_klo[pn] - 1, khi = s_khi[pn];   // a cell reaches k or k + 1 of the next frame
+        // Only the word counts that can be finite are computed, plus one column on either side that frame t - 1 may read
+        // (written as -inf): cells [kb0, kb1] of every record.
+        const int kb0 = max(klo - 1, 0), kb1 = min(khi + 1, n), KW = kb1 - kb0 + 1;
+        int my_lo = 0x7fffffff, my_hi = -1;
+        for (int64_t y = tid; y < (int64_t)n0 * KW; y += kSearchThreads) {
+            const int i = (int)(y / KW), k = kb0 + (int)(y % KW);
+            const int64_t x = (int64_t)i * N1 + k;
+            const int4 me = rinfo[b0 + i];
+            if (k == kb0) slot0[me.x] = (int)(b0 + i);
+            const float a = __int_as_float(me.y);
+            float m = ninf;
+            double mx = -INFINITY, acc = 0.0;
+            const int narc = (k < klo || k > khi) ? 0 : me.w;
+            for (int e = 0; e < narc; ++e) {
+                const int4 rec = orec[me.z + e];
+                const int ax = aux[rec.w];
+                int k2 = k;
+                if (ax > 0) {
+                    if (k >= n || W[k] != ax) continue;
+                    k2 = k + 1;
+                }
+                const int d = rec.x;
+                const int64_t j = ld_fresh(slot1 + d);
+                if (j < b1 || j >= b1 + n1 || rinfo[j].x != d) continue;
+                const float we = __int_as_float(rec.z) + erow[direct ? rec.y : labels[rec.y]];
+                const float vb = we + bt[j];
+                if (!(vb > ninf) || !(a + vb >= thresh)) continue;       // not an arc of the output lattice
+                const int64_t c = (j - b1) * N1 + k2;
+                const double v = (double)we + ld_fresh(Ln + c);
+                m = max(m, we + ld_fresh(Mn + c));
+                if (v > mx) { acc = acc * exp(mx - v) + 1.0; mx = v; }
+                else if (v > -INFINITY) acc += exp(v - mx);
+            }
+            L[x] = acc > 0.0 ? mx + log(acc) : -INFINITY;
+            M[x] = m;
+            if (acc > 0.0) { my_lo = min(my_lo, k); my_hi = max(my_hi, k); }
+        }
+        if (my_hi >= 0) { atomicMin(&s_klo[pc], my_lo); atomicMax(&s_khi[pc], my_hi); }
+        __syncthreads();
+        if (tid == 0) { s_klo[pn] = 0x7fffffff; s_khi[pn] = -1; }   // (frame t - 1 collects into it; read again only after its barrier)
+        __syncthreads();
+    }
+    // (the start record's cell k = 0: written only when frame 0's band of finite word counts reaches down to 0)
+    if (tid == 0) {
+        if (s_klo[T & 1] == 0) put(ld_fresh(Lr[T & 1] + 0), ld_fresh(Mr[T & 1] + 0));
+        else put(-INFINITY, ninf);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side: workspace planning and launches
 // ------------------------------------------------------------------------------------------
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -7449,10 +7591,12 @@ extern "C" int wf_viterbi(const void* graph_host, const void* graph_dev, const i
 namespace {
 struct SearchPlan {
     Plan P;   // only P.utt (utterance table followed by the search table) and P.off_utt are used
-    size_t off_best = 0, off_lsum = 0, off_slot = 0, off_cand = 0, off_cpk = 0, off_cls = 0, off_arcown = 0, off_xs = 0, off_xv = 0, off_xl = 0, off_xa = 0, off_arena = 0, off_ctl = 0, off_rinfo = 0, off_bt = 0, off_bl = 0, off_ftab = 0, total = 0;
+    size_t off_best = 0, off_lsum = 0, off_slot = 0, off_cand = 0, off_cpk = 0, off_cls = 0, off_arcown = 0, off_xs = 0, off_xv = 0, off_xl = 0, off_xa = 0, off_arena = 0, off_ctl = 0, off_rinfo = 0, off_bt = 0, off_bl = 0, off_ftab = 0, off_wl = 0, off_wt = 0, total = 0;
     int64_t nstates = 0;
     int wgs = 1;
     int ftab_stride = 0;   // (lattice: longest segment + 2)
+    int wstride = 0;       // (words: longest word sequence + 1)
+    size_t tab_words = 0;  // int64 words of the utterance + search tables (the word tables follow them in P.utt)
 };
 // Workgroups per utterance (search_mw_kernel when > 1): up to 8 while the launch fills at most half of the chip, and only
 // where the active set may grow past what one workgroup handles well.  WF_SEARCH_WGS forces a number (1: search_kernel).
@@ -7471,7 +7615,7 @@ int search_wgs(int B, int max_active) {
     return g;
 }
 int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg, int B, int V, int max_active,
-                bool logsum, bool lattice, SearchPlan* S) {
+                bool logsum, bool lattice, SearchPlan* S, const int32_t* words = nullptr, const int32_t* word_off = nullptr) {
     int rc = check_blob(graph_host);
     if (rc) return rc;
     if (B < 1 || !seg || V < 1) return wf_fail(WF_EINVAL, "bad B/seg/V");
@@ -7502,6 +7646,32 @@ int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* s
         S->ftab_stride = std::max(S->ftab_stride, T + 2);
     }
     S->nstates = ns;
+    S->tab_words = S->P.utt.size();
+    int64_t ncell = 0;
+    if (word_off) {   // search_words_kernel: per utterance the ring's first cell, then [n, words...] rows (int32, packed)
+        if (!words && word_off[B] > 0) return wf_fail(WF_EINVAL, "null words");
+        for (int i = 0; i < B; ++i) {
+            const int n = word_off[i + 1] - word_off[i];
+            if (n < 0) return wf_fail(WF_EINVAL, "word_off must not decrease");
+            S->wstride = std::max(S->wstride, n + 1);
+        }
+        std::vector<int32_t> rows((size_t)B * S->wstride + 1, 0);
+        for (int i = 0; i < B; ++i) {
+            const int n = word_off[i + 1] - word_off[i];
+            const int64_t cap = S->P.utt[(size_t)B * WF_U_WORDS + (size_t)i * WF_SR_WORDS + WF_SR_CAP];
+            S->P.utt.push_back(ncell);
+            ncell += 2 * cap * (n + 1);
+            rows[(size_t)i * S->wstride] = n;
+            for (int k = 0; k < n; ++k) {
+                const int w = words[word_off[i] + k];
+                if (w <= 0) return wf_fail(WF_EINVAL, "word ids must be > 0 (0 is epsilon)");
+                rows[(size_t)i * S->wstride + 1 + k] = w;
+            }
+        }
+        const size_t at = S->P.utt.size();
+        S->P.utt.resize(at + (rows.size() + 1) / 2, 0);
+        memcpy(&S->P.utt[at], rows.data(), rows.size() * sizeof(int32_t));
+    }
     const size_t W = (size_t)(S->wgs = search_wgs(B, max_active));   // (every workgroup of an utterance lists its own candidates)
     size_t o = 0;
     S->P.off_utt = o; o = align_up(o + sizeof(int64_t) * S->P.utt.size(), 256);
@@ -7523,6 +7693,10 @@ int plan_search(const void* graph_host, const int32_t* utt2fsa, const int32_t* s
         S->off_bt = o; o = align_up(o + 4 * (size_t)nr, 256);
         S->off_bl = o; o = align_up(o + 8 * (size_t)nr, 256);
         S->off_ftab = o; o = align_up(o + 8 * (size_t)B * S->ftab_stride, 256);
+    }
+    if (word_off) {
+        S->off_wl = o; o = align_up(o + 8 * (size_t)ncell, 256);
+        S->off_wt = o; o = align_up(o + 4 * (size_t)ncell, 256);
     }
     S->total = o;
     return WF_OK;
@@ -7554,7 +7728,9 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
                 int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B, int32_t Tmax,
                 float search_beam, int32_t min_active_states, int32_t max_active_states, uint32_t flags,
                 float* best_score, int32_t* best_arcs, void* tot_log, int32_t* n_active, void* workspace,
-                size_t workspace_bytes, void* stream, bool lattice, float output_beam, int64_t* lattice_arcs) {
+                size_t workspace_bytes, void* stream, bool lattice, float output_beam, int64_t* lattice_arcs,
+                const int32_t* aux_dev = nullptr, const int32_t* words = nullptr, const int32_t* word_off = nullptr,
+                void* tot_w = nullptr, float* best_w = nullptr) {
     if (!graph_dev || !log_probs || !best_score || !best_arcs || !workspace || !seg) return wf_fail(WF_EINVAL, "wf_search: null pointer");
     if (!(search_beam > 0.f)) return wf_fail(WF_EINVAL, "wf_search: search_beam must be > 0 (inf: no beam)");
     if (min_active_states < 0) return wf_fail(WF_EINVAL, "wf_search: min_active_states < 0");
@@ -7564,7 +7740,7 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
     SearchPlan S;
     // (with the lattice pass the total comes from search_back_kernel: the forward kernels skip their log-semiring pass)
     const bool fwd_log = tot_log != nullptr && !lattice;
-    rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, fwd_log, lattice, &S);
+    rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, fwd_log, lattice, &S, words, word_off);
     if (rc) return rc;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     if (ws + S.total > (unsigned char*)workspace + workspace_bytes) return wf_fail(WF_ENOSPC, "workspace too small: %zu < %zu", workspace_bytes, S.total + 256);
@@ -7632,6 +7808,18 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
             b.wgs = 1; b.redo = 1; b.test_drop = 0;   // what the barrier gave up on: one workgroup, from the start
         }
         hipLaunchKernelGGL(search_back_kernel, dim3(B), dim3(kSearchThreads), 0, st, b);
+        if (word_off) {   // the output lattice restricted to each utterance's word sequence
+            SearchWordsArgs w{};
+            w.b = b; w.b.redo = 0; w.b.ctl = nullptr;
+            w.aux = aux_dev;
+            w.woff = a.utt + S.tab_words;
+            w.wtab = (const int32_t*)(w.woff + B);
+            w.wstride = S.wstride;
+            w.wl = (double*)(ws + S.off_wl);
+            w.wt = (float*)(ws + S.off_wt);
+            w.tot_w = tot_w; w.best_w = best_w;
+            hipLaunchKernelGGL(search_words_kernel, dim3(B), dim3(kSearchThreads), 0, st, w);
+        }
     }
     HIP_TRY(hipGetLastError());
     return WF_OK;
@@ -7646,6 +7834,30 @@ extern "C" int wf_search(const void* graph_host, const void* graph_dev, const in
     return search_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, V, seg, B, Tmax, search_beam,
                        min_active_states, max_active_states, flags, best_score, best_arcs, tot_log, n_active, workspace,
                        workspace_bytes, stream, false, 0.f, nullptr);
+}
+
+extern "C" int wf_search_lattice_words_workspace_bytes(const void* graph_host, const int32_t* utt2fsa, const int32_t* seg,
+                                                       int32_t B, int32_t V, int32_t max_active_states,
+                                                       const int32_t* words, const int32_t* word_off, size_t* bytes) {
+    if (!bytes || !word_off) return wf_fail(WF_EINVAL, "null bytes / word_off");
+    SearchPlan S;
+    int rc = plan_search(graph_host, utt2fsa, seg, B, V, max_active_states, false, true, &S, words, word_off);
+    if (rc) return rc;
+    *bytes = S.total + 256;
+    return WF_OK;
+}
+
+extern "C" int wf_search_lattice_words(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,
+                                       int64_t strideB, int64_t strideT, int32_t num_seqs, int32_t V, const int32_t* seg, int32_t B,
+                                       int32_t Tmax, float search_beam, float output_beam, int32_t min_active_states,
+                                       int32_t max_active_states, uint32_t flags, const int32_t* aux_dev, const int32_t* words,
+                                       const int32_t* word_off, float* best_score, int32_t* best_arcs, void* tot_log,
+                                       void* tot_words, float* best_words, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!tot_log || !aux_dev || !word_off || !tot_words || !best_words) return wf_fail(WF_EINVAL, "wf_search_lattice_words: null pointer");
+    if (!(output_beam > 0.f)) return wf_fail(WF_EINVAL, "wf_search_lattice_words: output_beam must be > 0 (inf: no pruning)");
+    return search_impl(graph_host, graph_dev, utt2fsa, log_probs, strideB, strideT, num_seqs, V, seg, B, Tmax, search_beam,
+                       min_active_states, max_active_states, flags, best_score, best_arcs, tot_log, nullptr, workspace,
+                       workspace_bytes, stream, true, output_beam, nullptr, aux_dev, words, word_off, tot_words, best_words);
 }
 
 extern "C" int wf_search_lattice(const void* graph_host, const void* graph_dev, const int32_t* utt2fsa, const float* log_probs,

@@ -31,7 +31,8 @@ from .graph import best_path, tot_scores
 from .graph import pruned_search
 
 __all__ = ["DenseLattice", "OneBest", "get_lattice", "intersect_dense", "one_best_decoding", "shortest_path",
-           "get_aux_labels", "load_decoding_graph", "save_decoding_graph"]
+           "get_aux_labels", "load_decoding_graph", "save_decoding_graph", "linear_fst", "connect", "compose_words",
+           "compose", "WordFst", "DenseLatticeW", "invert"]
 
 
 class DenseLattice:
@@ -105,6 +106,113 @@ def intersect_dense(a_fsas, b_fsas, output_beam, max_states=15000000, max_arcs=1
     """k2.intersect_dense(graphs, dense_fsa_vec, output_beam) (graph.py:61-62, lattice_analysis.py:147,153)."""
     B = b_fsas.supervision_segments.shape[0]
     return DenseLattice(_as_vec(a_fsas, B), b_fsas)
+
+
+class WordFst:
+    """k2.linear_fst(labels, aux_labels) as lattice_analysis.py:137,143 uses it (W = k2.linear_fst(words, words)): per
+    utterance a word sequence to restrict a lattice or a decoding graph to."""
+
+    def __init__(self, words):
+        self.words = [[int(w) for w in ws] for ws in words]
+
+
+def linear_fst(labels, aux_labels=None):
+    """k2.linear_fst (lattice_analysis.py:137,143).  labels: a list of word-id lists (one per utterance)."""
+    if labels and not isinstance(labels[0], (list, tuple)):
+        labels = [labels]
+    return WordFst(labels)
+
+
+def invert(x):
+    """k2.invert as lattice_analysis.py:126 uses it -- twice in a row, to turn ragged aux labels into a tensor: the pair
+    is the identity, and so is this (a lattice here is not materialised; aux labels are one id per arc already)."""
+    return x
+
+
+def connect(x):
+    """k2.connect (lattice_analysis.py:139,140,145): compose() below only ever builds trimmed results."""
+    return x
+
+
+class DenseLatticeW:
+    """`k2.connect(k2.compose(lattice, W))` (lattice_analysis.py:139), not materialised: the search's lattice and the word
+    sequences; get_tot_scores runs wf_search_lattice_words."""
+
+    def __init__(self, lattice, wfst):
+        if lattice.search is None:
+            raise ValueError("compose(lattice, W): the lattice of intersect_dense is the whole product -- compose the "
+                             "decoding graph with W instead (lattice_analysis.py:140)")
+        self.lattice, self.words = lattice, wfst.words
+        self._res = {}
+
+    def get_tot_scores(self, use_double_scores: bool, log_semiring: bool):
+        from .graph import lattice_words
+        key = bool(use_double_scores)
+        if key not in self._res:
+            s = self.lattice.search
+            self._res[key] = lattice_words(self.lattice.graph, self.lattice.dense, self.words, s["search_beam"],
+                                           s.get("output_beam"), s["min_active_states"], s["max_active_states"], key)
+        r = self._res[key]
+        if log_semiring:
+            return r["tot_words"]
+        return r["best_words"].double() if use_double_scores else r["best_words"]
+
+
+def compose(a, b, treat_epsilons_specially=True):
+    """k2.compose as utils/lattice_analysis.py:139,140,145 calls it, with W = linear_fst(words, words) on the right:
+    compose(lattice, W) -> the lattice restricted to W (DenseLatticeW); compose(TLG, W) -> the decoding graph restricted to
+    W (compose_words; one graph per word sequence)."""
+    if not isinstance(b, WordFst):
+        raise TypeError("compose: the right-hand side must be linear_fst(words, words)")
+    if isinstance(a, DenseLattice):
+        return DenseLatticeW(a, b)
+    if isinstance(a, Fsa):
+        gs = [compose_words(a, w) for w in b.words]
+        return gs[0] if len(gs) == 1 else create_fsa_vec(gs)
+    raise TypeError("compose: expected a lattice or a decoding graph on the left")
+
+
+def compose_words(graph: Fsa, words):
+    """`k2.connect(k2.compose(TLG, W))` for a linear word acceptor W (lattice_analysis.py:140,145): the decoding graph
+    restricted to the paths whose non-epsilon aux labels spell `words`.  Product states (k words consumed, state), built
+    with numpy and trimmed to the states that lie on a complete path (scipy BFS both ways); arcs stay sorted by source
+    state, the start state stays 0 and the super-final state stays last.  Host-side graph work, like compile_TLG's."""
+    import numpy as np
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import breadth_first_order
+    assert graph.num_fsas == 1 and graph.aux_labels is not None
+    a = graph.arcs
+    src, dst, lab, aux = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64), a[:, 2], graph.aux_labels
+    S = int(graph.fsa_num_states[0])
+    n = len(words)
+    em, fin = lab >= 0, lab < 0
+    eps = np.nonzero(em & (aux <= 0))[0]
+    parts_src, parts_dst, parts_arc = [], [], []
+    for k in range(n + 1):
+        parts_src.append(k * S + src[eps]); parts_dst.append(k * S + dst[eps]); parts_arc.append(eps)
+        if k < n:
+            w = np.nonzero(em & (aux == int(words[k])))[0]
+            parts_src.append(k * S + src[w]); parts_dst.append((k + 1) * S + dst[w]); parts_arc.append(w)
+    FINAL = (n + 1) * S
+    f = np.nonzero(fin)[0]
+    parts_src.append(n * S + src[f]); parts_dst.append(np.full(f.size, FINAL, dtype=np.int64)); parts_arc.append(f)
+    ps, pd, pa = np.concatenate(parts_src), np.concatenate(parts_dst), np.concatenate(parts_arc)
+    N = FINAL + 1
+    ones = np.ones(ps.size, dtype=np.int8)
+    fwd = breadth_first_order(csr_matrix((ones, (ps, pd)), shape=(N, N)), 0, directed=True, return_predecessors=False)
+    bwd = breadth_first_order(csr_matrix((ones, (pd, ps)), shape=(N, N)), FINAL, directed=True, return_predecessors=False)
+    keep = np.zeros(N, dtype=bool)
+    keep[np.intersect1d(fwd, bwd)] = True
+    if not (keep[0] and keep[FINAL]):
+        # no path spells these words: a start state and a final state without arcs (every total is -inf)
+        return Fsa(np.zeros((0, 4), dtype=np.int32), np.zeros(0, dtype=np.int32), [0, 0], [2])
+    ok = keep[ps] & keep[pd]
+    ps, pd, pa = ps[ok], pd[ok], pa[ok]
+    new_id = np.cumsum(keep) - 1                     # increasing in (k, state): 0 stays first, FINAL last
+    order = np.lexsort((pa, new_id[ps]))             # by source state, then by the original arc index
+    ps, pd, pa = ps[order], pd[order], pa[order]
+    arcs = np.stack([new_id[ps], new_id[pd], lab[pa].astype(np.int64), a[pa, 3].astype(np.int64)], 1).astype(np.int32)
+    return Fsa(arcs, aux[pa].astype(np.int32), [0, arcs.shape[0]], [int(keep.sum())])
 
 
 def one_best_decoding(lattice, use_double_scores=True):

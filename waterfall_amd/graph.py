@@ -622,3 +622,47 @@ def pruned_search(graph: Fsa, dense: DenseFsaVec, search_beam: float = 20.0, min
         res["lattice_arcs"] = narcs
     return res
 
+
+
+def lattice_words(graph: Fsa, dense: DenseFsaVec, words, search_beam: float = 20.0, output_beam: float = 8.0,
+                  min_active_states: int = 30, max_active_states: int = 10000, use_double_scores: bool = True):
+    """The search's output lattice restricted to a word sequence per utterance (wf_search_lattice_words):
+    `latticeW = k2.connect(k2.compose(lattice, W))`, W = k2.linear_fst(words, words), utils/lattice_analysis.py:137-139.
+
+    words: one list of word ids (> 0, the graph's aux labels) per utterance.  Returns dict(scores, arcs: the lattice's best
+    path as pruned_search; tot_log: the lattice's total; tot_words / best_words: log-semiring and tropical totals over the
+    lattice's paths that spell the words, -inf when it holds none).  output_beam None or inf: no backward pruning."""
+    lp, seg, B = _check_inputs(graph, dense)
+    if graph.aux_labels is None:
+        raise ValueError("lattice_words: the graph has no aux labels (word ids)")
+    if len(words) != B:
+        raise ValueError(f"lattice_words: {len(words)} word sequences for {B} segments")
+    lib = _lib.lib()
+    dev = lp.device
+    N, T, V = lp.shape
+    flags = _lib.WF_DOUBLE_ACC if use_double_scores else 0
+    ob = float("inf") if output_beam is None else float(output_beam)
+    woff = np.zeros(B + 1, dtype=np.int32)
+    woff[1:] = np.cumsum([len(w) for w in words])
+    wflat = np.asarray([int(x) for w in words for x in w] or [0], dtype=np.int32)
+    aux = graph.__dict__.get("_aux_dev", {}).get(str(dev))
+    if aux is None:
+        aux = torch.from_numpy(np.ascontiguousarray(graph.aux_labels, dtype=np.int32)).to(dev)
+        graph.__dict__.setdefault("_aux_dev", {})[str(dev)] = aux
+    n = C.c_size_t(0)
+    _lib.check(lib.wf_search_lattice_words_workspace_bytes(_np_ptr(graph.blob_host()), _np_ptr(graph.utt2fsa), _np_ptr(seg), B, V,
+                                                            int(max_active_states), _np_ptr(wflat), _np_ptr(woff), C.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    ft = torch.float64 if use_double_scores else torch.float32
+    scores = torch.empty(B, dtype=torch.float32, device=dev)
+    arcs = torch.empty((B, T + 1), dtype=torch.int32, device=dev)
+    tot = torch.empty(B, dtype=ft, device=dev)
+    totw = torch.empty(B, dtype=ft, device=dev)
+    bestw = torch.empty(B, dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.check(lib.wf_search_lattice_words(_np_ptr(graph.blob_host()), _ptr(graph.blob_dev(dev)), _np_ptr(graph.utt2fsa),
+                                               _ptr(lp), lp.stride(0), lp.stride(1), N, V, _np_ptr(seg), B, T,
+                                               float(search_beam), ob, int(min_active_states), int(max_active_states), flags,
+                                               _ptr(aux), _np_ptr(wflat), _np_ptr(woff), _ptr(scores), _ptr(arcs), _ptr(tot),
+                                               _ptr(totw), _ptr(bestw), _ptr(ws), n.value, _stream(dev)))
+    return {"scores": scores, "arcs": arcs, "tot_log": tot, "tot_words": totw, "best_words": bestw}
