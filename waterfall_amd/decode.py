@@ -4,6 +4,8 @@
     lattice.get_tot_scores(True, True) / (True, False)                                       # :128-129
     one_best = one_best_decoding(lattice); get_aux_labels(one_best); one_best.labels         # :133-135
     ETLGW = intersect_dense(TLGW, dense_fsa_vec, 10); ETLGW.get_tot_scores(True, True)        # :147-149
+    W = arc_sort(linear_fst(words, words)); latticeW = connect(compose(lattice, W)); TLGW = connect(compose(TLG, W))  # :137-140
+    latticeW.get_tot_scores(True, True) / (True, False)                                      # :161-162
     shortest_path(lattice, True)                                                             # :79
     TLG = load_decoding_graph("data/lang/TLG.pt")                                            # :199, compile_TLG.py:122-129
 
