@@ -584,7 +584,16 @@ def search_bench(dev, S, B=8, T=500, V=5001, beam=20.0, max_active=10000, reps=3
     ms_log, out2 = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, max_active, log_tot=True, return_active=True))
     # get_lattice's output_beam (lattice_analysis.sh's lattice_beam = 8): the backward launch over the finished lattice
     ms_lat, out3 = timed(lambda: wf.pruned_search(fsa, dense, beam, 30, max_active, log_tot=True, output_beam=8.0))
+    # ... and that lattice restricted to the best path's word sequence (compose(lattice, W), lattice_analysis.py:137-139):
+    # word labels on ~4 % of the arcs (~16 words per utterance), as tools/time_lattice_words.py
+    rng = np.random.default_rng(1)
+    lab = fsa.arcs[:, 2]
+    fsa.aux_labels = np.where(lab >= 0, np.where(rng.random(lab.size) < 0.04, rng.integers(1, 1000, lab.size), 0), -1).astype(np.int32)
+    words = wf.pruned_search(fsa, dense, beam, 30, max_active, log_tot=False)["aux_labels"]
+    ms_w, outw = timed(lambda: wf.lattice_words(fsa, dense, words, beam, 8.0, 30, max_active))
     return {"ms_per_call": ms, "ms_per_call_with_log_total": ms_log, "ms_per_call_with_output_beam8": ms_lat,
+            "ms_per_call_lattice_restricted_to_words": ms_w,
+            "mean_P_words_in_lattice_over_P_lattice": float(torch.exp(outw["tot_words"] - outw["tot_log"]).mean().item()),
             "lattice_arcs_per_frame_output_beam8": float(out3["lattice_arcs"].double().mean().item()) / T,
             "log_total_minus_output_beam8_total": float((out2["tot_log"].double() - out3["tot_log"].double()).mean().item()),
             "exact_sweep_ms_per_call": ms_exact,
