@@ -458,3 +458,28 @@ def test_lattice_analysis_ratios_with_the_reference_calls():
     np.testing.assert_allclose(TLG_W_total_score.item(), o.forward(gw, lp[0], 30)[1], rtol=1e-9)
     np.testing.assert_allclose(TLG_W_total_score.item(), o.lattice_words(g, lp[0], 30, words)[0], rtol=1e-9)   # two routes
     np.testing.assert_allclose(lattice_total_score.item(), o.lattice_search(g, lp[0], 30, 12.0, 6.0)[2], rtol=1e-9)
+
+
+@pytest.mark.parametrize("drop", [4, 7])
+def test_words_pass_survives_a_workgroup_that_never_arrives(drop, search_kernel_variant):
+    import os
+    if search_kernel_variant != "four_workgroups_every_frame_shared":
+        pytest.skip("the hook only acts on the multi-workgroup kernels")
+    g, lp, segs, one, fsa, dense = _word_graph(12_001, B=3, T=22, seed=35)
+    kw = dict(search_beam=8.0, output_beam=4.0, min_active_states=0, max_active_states=0)
+    words = wf.pruned_search(fsa, dense, use_double_scores=True, **kw)["aux_labels"]
+    want = wf.lattice_words(fsa, dense, words, **kw)
+    os.environ["WF_SEARCH_TEST_DROP"] = str(drop)
+    try:
+        got = wf.lattice_words(fsa, dense, words, **kw)
+    finally:
+        os.environ.pop("WF_SEARCH_TEST_DROP", None)
+    for k in ("scores", "arcs", "best_words"):
+        assert torch.equal(got[k], want[k]), k
+    np.testing.assert_allclose(got["tot_words"].cpu().numpy(), want["tot_words"].cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(got["tot_log"].cpu().numpy(), want["tot_log"].cpu().numpy(), rtol=1e-12)
+    for i in range(3):
+        tw, bw = o.lattice_words(g, lp[i], int(segs[i, 2]), words[i], 8.0, 4.0)
+        assert got["best_words"][i].item() == bw
+        if np.isfinite(tw):
+            np.testing.assert_allclose(got["tot_words"][i].item(), tw, rtol=1e-9)

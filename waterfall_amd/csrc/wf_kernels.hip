@@ -4441,7 +4441,7 @@ struct SearchArgs {
     struct SearchCtl* ctl;       // [B], zeroed before the launch
     const int32_t* redo;         // search_kernel after search_mw_kernel: [B] stride of SearchCtl, run only the utterances whose flag is set
     int redo_stride;
-    int test_drop;               // test aid (WF_SEARCH_TEST_DROP, bit 0: search_mw_kernel, bit 1: search_back_kernel): the utterance's last workgroup leaves at once, as if it had never
+    int test_drop;               // test aid (WF_SEARCH_TEST_DROP, bit 0: search_mw_kernel, bit 1: search_back_kernel, bit 2: search_words_kernel): the utterance's last workgroup leaves at once, as if it had never
                                  // become resident -- its partners' barrier runs out and the one-workgroup launch redoes the utterance
 };
 
@@ -4463,6 +4463,11 @@ struct SearchCtl {
     unsigned bbar;
     int babort;
     unsigned long long narcs;
+    // search_words_kernel: barrier counter, abort flag, and per frame (three generations, as c[]) the smallest and largest
+    // word count with a finite cell
+    unsigned wbar;
+    int wabort;
+    int kband[3][2];
 };
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -5590,9 +5595,12 @@ struct SearchWordsArgs {
 };
 
 __global__ void __launch_bounds__(kSearchThreads) search_words_kernel(SearchWordsArgs q) {
-    __shared__ int s_klo[2], s_khi[2];   // word counts that have a finite cell, per frame parity: the others are skipped
+    __shared__ int s_band[3][2];   // {smallest, largest} word count with a finite cell, frame t in generation (T - t) % 3
+    __shared__ int s_abort;
     const SearchBackArgs& p = q.b;
-    const int u = blockIdx.x, tid = threadIdx.x;
+    const int u = blockIdx.x % p.B, g = blockIdx.x / p.B, tid = threadIdx.x;
+    SearchCtl* ctl = p.ctl ? p.ctl + u : nullptr;
+    if (p.redo && !ctl->wabort) return;
     const int64_t* U = p.utt + (int64_t)u * WF_U_WORDS;
     const int64_t* R = p.tab + (int64_t)u * WF_SR_WORDS;
     const int32_t* I = p.blob + WF_HDR_WORDS + (int)U[WF_U_FSA] * WF_INFO_WORDS;
@@ -5604,9 +5612,42 @@ __global__ void __launch_bounds__(kSearchThreads) search_words_kernel(SearchWord
         q.best_w[u] = bw;
     };
     if (!(best > ninf)) {
-        if (tid == 0) put(-INFINITY, ninf);
+        if (tid == 0 && g == 0) put(-INFINITY, ninf);
         return;
     }
+    const int64_t* ftab = p.ftab + (int64_t)u * p.ftab_stride;
+    // as search_back_kernel: a wide lattice is shared by the utterance's workgroups (contiguous blocks of a frame's cells,
+    // one bounded barrier in device memory per frame, a one-workgroup second launch for what it gives up on)
+    const bool multi = p.wgs > 1 && ftab[T + 1] >= (int64_t)max(p.solo_max, 2) * (T + 1);
+    if (!multi && g != 0) return;
+    const int NW = multi ? p.wgs : 1;
+    unsigned nbar = 0;
+    if ((p.test_drop & 4) && multi && g == NW - 1) return;
+    auto sync_all = [&]() -> bool {
+        if (multi) drain_vm();
+        __syncthreads();
+        if (!multi) return false;
+        if (tid == 0) {
+            ++nbar;
+            const unsigned target = nbar * (unsigned)NW;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            drain_vm();
+            atomicAdd(&ctl->wbar, 1u);
+            long spins = 0;
+            bool ab = false;
+            while (ld_fresh(&ctl->wbar) < target) {
+                if (++spins > 64) __builtin_amdgcn_s_sleep(2);
+                if ((spins & 255) == 0 && (ld_fresh(&ctl->wabort) || spins > kSearchSpinLimit)) { ab = true; break; }
+            }
+            if (ab) atomicExch(&ctl->wabort, 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_vm();
+            s_abort = ab || ld_fresh(&ctl->wabort);
+        }
+        __syncthreads();
+        return s_abort != 0;
+    };
+    int (*band)[2] = multi ? ctl->kband : s_band;   // (device memory when several workgroups collect into it)
     const float thresh = best - p.output_beam;
     const int direct = I[WF_I_DIRECT];
     const int4* orec = (const int4*)(p.blob + I[WF_I_OUT_REC]);
@@ -5618,7 +5659,6 @@ __global__ void __launch_bounds__(kSearchThreads) search_words_kernel(SearchWord
     const int4* rinfo = p.rinfo + R[WF_SR_AOFF];
     const float* bt = p.bt + R[WF_SR_AOFF];
     const double* bl = p.bl + R[WF_SR_AOFF];
-    const int64_t* ftab = p.ftab + (int64_t)u * p.ftab_stride;
     const float* lp0 = p.lp + U[WF_U_SEQ] * p.strideB + U[WF_U_START] * p.strideT;
     const int32_t* W = q.wtab + (int64_t)u * q.wstride;
     const int n = W[0], N1 = n + 1;
@@ -5626,14 +5666,18 @@ __global__ void __launch_bounds__(kSearchThreads) search_words_kernel(SearchWord
     const int64_t cap = R[WF_SR_CAP];
     double* Lr[2] = {q.wl + q.woff[u], q.wl + q.woff[u] + cap * N1};
     float* Mr[2] = {q.wt + q.woff[u], q.wt + q.woff[u] + cap * N1};
-    // ---------------- frame T
-    {
+    // ---------------- frame T (workgroup 0)
+    if (g == 0) {
         const int64_t b1 = ftab[T];
         const int n1 = (int)(ftab[T + 1] - b1);
         int32_t* slot = slot_of(T);
-        double* L = Lr[(T - T) & 1];
-        float* M = Mr[(T - T) & 1];
-        if (tid == 0) { s_klo[0] = n; s_khi[0] = n; s_klo[1] = 0x7fffffff; s_khi[1] = -1; }
+        double* L = Lr[0];
+        float* M = Mr[0];
+        if (tid == 0) {
+            band[0][0] = n; band[0][1] = n;
+            band[1][0] = 0x7fffffff; band[1][1] = -1;
+            band[2][0] = 0x7fffffff; band[2][1] = -1;
+        }
         for (int64_t x = tid; x < (int64_t)n1 * N1; x += kSearchThreads) {
             const int i = (int)(x / N1), k = (int)(x % N1);
             const double l = bl[b1 + i];
@@ -5642,8 +5686,8 @@ __global__ void __launch_bounds__(kSearchThreads) search_words_kernel(SearchWord
             M[x] = end ? bt[b1 + i] : ninf;
             if (k == 0) slot[rinfo[b1 + i].x] = (int)(b1 + i);
         }
-        __syncthreads();
     }
+    if (sync_all()) return;
     // ---------------- frames T - 1 .. 0
     for (int t = T - 1; t >= 0; --t) {
         const int64_t b0 = ftab[t], b1 = ftab[t + 1];
@@ -5655,17 +5699,22 @@ __global__ void __launch_bounds__(kSearchThreads) search_words_kernel(SearchWord
         const float* Mn = Mr[(T - t - 1) & 1];
         double* L = Lr[(T - t) & 1];
         float* M = Mr[(T - t) & 1];
-        const int pn = (T - t - 1) & 1, pc = (T - t) & 1;
-        if (s_khi[pn] < 0) {   // (uniform) no cell of frame t + 1 is finite: the lattice holds no path with these words
-            if (tid == 0) put(-INFINITY, ninf);
+        const int gn = (T - t - 1) % 3, gc = (T - t) % 3, gp = (T - t + 1) % 3;   // frame t + 1's band, this frame's, frame t - 1's
+        const int blo = ld_fresh(&band[gn][0]), bhi = ld_fresh(&band[gn][1]);
+        if (bhi < 0) {   // (uniform) no cell of frame t + 1 is finite: the lattice holds no path with these words
+            if (tid == 0 && g == 0) put(-INFINITY, ninf);
             return;
         }
-        const int klo = s_klo[pn] - 1, khi = s_khi[pn];   // a cell reaches k or k + 1 of the next frame
+        // (frame t - 1 collects into generation gp, last read -- as frame t + 2's band -- before the barrier that ended frame t + 1)
+        if (tid == 0 && g == 0) { band[gp][0] = 0x7fffffff; band[gp][1] = -1; }
+        const int klo = blo - 1, khi = bhi;   // a cell reaches k or k + 1 of the next frame
         // Only the word counts that can be finite are computed, plus one column on either side that frame t - 1 may read
         // (written as -inf): cells [kb0, kb1] of every record.
         const int kb0 = max(klo - 1, 0), kb1 = min(khi + 1, n), KW = kb1 - kb0 + 1;
+        const int64_t ncell = (int64_t)n0 * KW;
+        const int64_t y0 = NW > 1 ? ncell * g / NW : 0, y1 = NW > 1 ? ncell * (g + 1) / NW : ncell;
         int my_lo = 0x7fffffff, my_hi = -1;
-        for (int64_t y = tid; y < (int64_t)n0 * KW; y += kSearchThreads) {
+        for (int64_t y = y0 + tid; y < y1; y += kSearchThreads) {
             const int i = (int)(y / KW), k = kb0 + (int)(y % KW);
             const int64_t x = (int64_t)i * N1 + k;
             const int4 me = rinfo[b0 + i];
@@ -5698,14 +5747,12 @@ __global__ void __launch_bounds__(kSearchThreads) search_words_kernel(SearchWord
             M[x] = m;
             if (acc > 0.0) { my_lo = min(my_lo, k); my_hi = max(my_hi, k); }
         }
-        if (my_hi >= 0) { atomicMin(&s_klo[pc], my_lo); atomicMax(&s_khi[pc], my_hi); }
-        __syncthreads();
-        if (tid == 0) { s_klo[pn] = 0x7fffffff; s_khi[pn] = -1; }   // (frame t - 1 collects into it; read again only after its barrier)
-        __syncthreads();
+        if (my_hi >= 0) { atomicMin(&band[gc][0], my_lo); atomicMax(&band[gc][1], my_hi); }
+        if (sync_all()) return;
     }
     // (the start record's cell k = 0: written only when frame 0's band of finite word counts reaches down to 0)
-    if (tid == 0) {
-        if (s_klo[T & 1] == 0) put(ld_fresh(Lr[T & 1] + 0), ld_fresh(Mr[T & 1] + 0));
+    if (tid == 0 && g == 0) {
+        if (ld_fresh(&band[T % 3][0]) == 0) put(ld_fresh(Lr[T & 1] + 0), ld_fresh(Mr[T & 1] + 0));
         else put(-INFINITY, ninf);
     }
 }
@@ -7810,7 +7857,7 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
         hipLaunchKernelGGL(search_back_kernel, dim3(B), dim3(kSearchThreads), 0, st, b);
         if (word_off) {   // the output lattice restricted to each utterance's word sequence
             SearchWordsArgs w{};
-            w.b = b; w.b.redo = 0; w.b.ctl = nullptr;
+            w.b = b; w.b.redo = 0; w.b.ctl = nullptr; w.b.wgs = 1;
             w.aux = aux_dev;
             w.woff = a.utt + S.tab_words;
             w.wtab = (const int32_t*)(w.woff + B);
@@ -7818,6 +7865,11 @@ int search_impl(const void* graph_host, const void* graph_dev, const int32_t* ut
             w.wl = (double*)(ws + S.off_wl);
             w.wt = (float*)(ws + S.off_wt);
             w.tot_w = tot_w; w.best_w = best_w;
+            if (S.wgs > 1) {
+                w.b.wgs = S.wgs; w.b.ctl = a.ctl; w.b.solo_max = a.solo_max; w.b.test_drop = a.test_drop;
+                hipLaunchKernelGGL(search_words_kernel, dim3(B * S.wgs), dim3(kSearchThreads), 0, st, w);
+                w.b.wgs = 1; w.b.redo = 1; w.b.test_drop = 0;
+            }
             hipLaunchKernelGGL(search_words_kernel, dim3(B), dim3(kSearchThreads), 0, st, w);
         }
     }
