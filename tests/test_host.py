@@ -350,3 +350,24 @@ def test_manual_ctc_matrices_to_fsa_vectorised_equals_the_loop():
     assert np.array_equal(a.fsa_arc_offsets, b_.fsa_arc_offsets) and np.array_equal(a.fsa_num_states, b_.fsa_num_states)
     with pytest.raises(ValueError):
         manual_ctc.matrices_to_fsa(tt, torch.tensor([0, 3, 17, 7]), tf)
+
+
+def test_lattice_analysis_graph_side_calls_on_the_host():
+    """utils/lattice_analysis.py:137-145 on the host: W = arc_sort(linear_fst(words, words)); connect(compose(TLG, W)) is
+    the decoding graph restricted to the word sequence (trimmed, arcs sorted by source, start 0, super-final last)."""
+    import waterfall_amd as k2
+    # start -a:1-> 1 -b:0-> 2 -c:2-> 3 -> final ; and a bypass 0 -d:3-> 3
+    arcs = [(0, 1, 5, -0.5), (0, 3, 6, -1.0), (1, 2, 7, -0.25), (2, 3, 8, -0.125), (3, 4, -1, 0.0)]
+    TLG = k2.Fsa.from_arcs(arcs, 5, aux_labels=[1, 3, 0, 2, -1])
+    W = k2.arc_sort(k2.linear_fst([[1, 2]], [[1, 2]]))
+    TLGW = k2.connect(k2.compose(TLG, W))
+    assert isinstance(TLGW, k2.Fsa) and TLGW.num_fsas == 1
+    a = TLGW.arcs
+    assert a.shape[0] == 4 and list(a[:, 2]) == [5, 7, 8, -1]              # the bypass (word 3) is gone
+    assert list(TLGW.aux_labels) == [1, 0, 2, -1]
+    assert np.all(np.diff(a[:, 0]) >= 0) and a[0, 0] == 0 and a[-1, 1] == int(TLGW.fsa_num_states[0]) - 1
+    assert k2.compose(TLG, k2.linear_fst([[3]], [[3]])).arcs.shape[0] == 2   # 0 -d:3-> 3 -> final
+    assert k2.compose(TLG, k2.linear_fst([[2, 1]], [[2, 1]])).arcs.shape[0] == 0
+    two = k2.compose(TLG, k2.linear_fst([[1, 2], [3]], [[1, 2], [3]]))
+    assert two.num_fsas == 2
+    assert k2.invert(k2.invert(TLG)) is TLG
