@@ -350,7 +350,8 @@ int wf_viterbi(const void* graph_host, const void* graph_dev, const int32_t* utt
 
 /* ---- beam-pruned frame-synchronous search (k2.get_lattice(log_prob, log_prob_len, TLG, search_beam, output_beam,
  * min_active_states, max_active_states), utils/lattice_analysis.py:125 with the beams of lattice_analysis.sh:9-11) --------
- * Token passing over the outgoing arcs of a decoding graph of any size; one workgroup per utterance.  A state of frame t
+ * Token passing over the outgoing arcs of a decoding graph of any size; one workgroup per utterance, or several (up to 8
+ * while the launch fills at most half of the chip) with a bounded barrier in device memory between them.  A state of frame t
  * survives when its tropical score is within search_beam of the frame's best; when more than max_active_states survive
  * (0: no limit) or fewer than min_active_states, the cut-off moves along a 1024-bin histogram of the frame's scores.
  * search_beam = +inf with max_active_states = 0 is the exact search (scores and arcs equal wf_viterbi's bit for bit).
