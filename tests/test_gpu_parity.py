@@ -1352,6 +1352,13 @@ def test_several_supervision_segments_per_sequence(topo, den, beam, reduction):
             gi = o.graphloss([c["ographs"][i]], c["lp"][:3], segs[i:i + 1], beam, "sum")[1]
             gwant += (i + 1) * gi
     np.testing.assert_allclose(lp.grad.cpu().numpy(), gwant, atol=GRAD_ATOL * (6 if reduction == "none" else 1))
+    if reduction == "sum" and beam is None:   # the other autograd node (use_double_scores: wf_fb_logsum + wf_fb_backward)
+        lp2 = torch.from_numpy(c["lp"][:3]).to(DEV).requires_grad_(True)
+        l2 = wf.graphloss(c["fsa"], wf.DenseFsaVec(lp2, torch.from_numpy(segs)), output_beam=None, reduction="sum",
+                          use_double_scores=True)
+        l2.backward()
+        np.testing.assert_allclose(l2.item(), want, rtol=TOT_RTOL, atol=TOT_ATOL)
+        np.testing.assert_allclose(lp2.grad.cpu().numpy(), gwant, atol=GRAD_ATOL)
     # forward-only entry points take such batches as they are
     tot = wf.tot_scores(c["fsa"], wf.DenseFsaVec(lp.detach(), torch.from_numpy(segs)), True, True).cpu().numpy()
     bp = wf.best_path(c["fsa"], wf.DenseFsaVec(lp.detach(), torch.from_numpy(segs)))
