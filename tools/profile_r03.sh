@@ -18,6 +18,7 @@ st cfg2num $B --workload cfg2_2state_char_num
 st cfg5 tools/search_bench.py 1000000
 st fresh tools/time_fresh.py
 st search2k tools/search_active_sweep.py 2.6 2.3 2.0
+st latw tools/time_lattice_words.py 10 2.6 2.3
 pm fetch FETCH_SIZE $B
 pm write WRITE_SIZE $B
 pm fetchp FETCH_SIZE $B --output-beam 10
@@ -28,7 +29,7 @@ pm fetch43 FETCH_SIZE $B --workload cfg4_3state-skip_bpe5k_den
 pm write43 WRITE_SIZE $B --workload cfg4_3state-skip_bpe5k_den
 pm fetch5 FETCH_SIZE tools/bench_viterbi.py 1000000
 pm write5 WRITE_SIZE tools/bench_viterbi.py 1000000
-for n in cfg3 cfg3p cfg4den cfg4den3 cfg2den cfg2num cfg5 fresh search2k; do python3 tools/prof_summary.py $O/${n}_results.db > $O/${n}_kernel_stats.txt || exit 1; done
+for n in cfg3 cfg3p cfg4den cfg4den3 cfg2den cfg2num cfg5 fresh search2k latw; do python3 tools/prof_summary.py $O/${n}_results.db > $O/${n}_kernel_stats.txt || exit 1; done
 python3 tools/pmc_traffic.py $O/fetch_results.db $O/write_results.db "cfg3_ctc_bpe5k_num B=32 T=500" > $O/pmc_traffic.json || exit 1
 python3 tools/pmc_traffic.py $O/fetchp_results.db $O/writep_results.db "cfg3_ctc_bpe5k_num B=32 T=500 output_beam=10" > $O/pmc_traffic_cfg3_pruned.json || exit 1
 python3 tools/pmc_traffic.py $O/fetch4_results.db $O/write4_results.db "cfg4_mmictc_bpe5k_den B=32 T=500" > $O/pmc_traffic_cfg4den.json || exit 1

@@ -15,6 +15,8 @@ cp $S/fresh_kernel_stats.txt profiles/r03_fresh_graphs_kernel_stats.txt
 cp $S/fresh.json profiles/r03_fresh_graphs_timings.txt
 cp $S/search2k_kernel_stats.txt profiles/r03_search_active_sweep_kernel_stats.txt
 cp $S/search2k.json profiles/r03_search_active_sweep_timings.txt
+cp $S/latw_kernel_stats.txt profiles/r03_lattice_words_kernel_stats.txt
+cp $S/latw.json profiles/r03_lattice_words_timings.txt
 cp $S/pmc_traffic.json profiles/r03_pmc_traffic.json
 cp $S/pmc_traffic_cfg3_pruned.json profiles/r03_pmc_traffic_cfg3_pruned_beam10.json
 cp $S/pmc_traffic_cfg4den.json profiles/r03_pmc_traffic_cfg4_mmictc_den.json
